@@ -1,0 +1,115 @@
+/*
+ * surfacenet_hip.h — C ABI of libsurfacenet_hip.so (MI355X / gfx950).
+ *
+ * The reference (mjiUST/SurfaceNet) has no FFI: its hot path is three Python callables used in
+ * main_reconstruct.py:134-146. This header is what a ctypes binding of those callables needs; each
+ * entry point cites the reference interface it replaces (paths relative to the reference root).
+ * The Python side that presents the reference's own signatures on top of this ABI lives in
+ * surfacenet_amd/CVC.py and surfacenet_amd/SurfaceNet.py.
+ *
+ * Conventions: plain C; every pointer is caller-owned HOST memory unless the parameter name ends in
+ * `_dev` (device memory of the context's GPU); functions returning int give 0 on success and a
+ * negative sn_status on failure, with a human-readable message from sn_last_error() (thread-local).
+ * One sn_ctx per GPU per host thread; a context is not thread-safe, the library has no global state.
+ * All work of a context is issued on one HIP stream owned by the context; host-pointer entry points
+ * are synchronous, `_dev` entry points are asynchronous until sn_synchronize().
+ */
+#ifndef SURFACENET_HIP_H
+#define SURFACENET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_ABI_VERSION 1
+
+typedef struct sn_ctx sn_ctx;
+
+enum sn_status {
+    SN_OK = 0,
+    SN_ERR_ARG = -1,     /* bad argument (shape, null pointer, view id out of range ...) */
+    SN_ERR_STATE = -2,   /* call order: weights / images / cameras not set                */
+    SN_ERR_HIP = -3,     /* HIP runtime error; text carries hipGetErrorString             */
+    SN_ERR_NOMEM = -4,
+    SN_ERR_COMM = -5
+};
+
+/* One parameter array inside the weight blob (reference pickle = flat list of arrays,
+ * nets/SurfaceNet.py:397-400; order documented in SURVEY.md App. B / DESIGN.md). */
+typedef struct {
+    int64_t offset;   /* in floats, into `blob` */
+    int32_t ndim;
+    int32_t shape[5];
+} sn_param_desc;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* cube_D = s of the s^3 colored voxel cube (params.py:65, 32 or 64; any multiple of 4 >= 8 is
+ * accepted for tests); max_samples = largest n*n_vp processed per internal pass (activation
+ * workspace is sized for it; larger calls are chunked). Returns NULL on failure (sn_last_error). */
+sn_ctx *sn_create(int device_id, int cube_D, int max_samples);
+void sn_destroy(sn_ctx *ctx);
+const char *sn_last_error(void);
+int sn_version(void);
+int sn_synchronize(sn_ctx *ctx);
+
+/* ---- one-time setup -------------------------------------------------------------------------- */
+/* Replaces lasagne.layers.set_all_param_values(...) in SurfaceNet_inference
+ * (nets/SurfaceNet.py:385-402). `descs` lists the 105 arrays of the reference pickle in its order
+ * (98 for the network alone: the relative-weight MLP arrays may be omitted). BN folding and the
+ * fp16 MFMA-fragment packing happen inside. */
+int sn_load_weights(sn_ctx *ctx, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params);
+/* models_img of CVC.gen_coloredCubes (utils/CVC.py:56): V images, (H[v], W[v], 3) uint8 RGB. */
+int sn_set_images(sn_ctx *ctx, int V, const uint8_t *const *imgs, const int *H, const int *W);
+/* cameraPOs of CVC.gen_coloredCubes: (V,3,4) float64 row-major projection matrices. */
+int sn_set_cameras(sn_ctx *ctx, int V, const double *P);
+
+/* ---- hot path, host buffers ------------------------------------------------------------------ */
+/* CVC.gen_coloredCubes (utils/CVC.py:56-104) [+ CVC.preprocess_augmentation, utils/CVC.py:108-111,
+ * when mean6 != NULL]. view_pairs (n, n_vp, 2) int64 indices into the image/camera lists;
+ * xyz (n,3) float32 cube min corners; resol (n,) float32; out (n*n_vp, 6, s,s,s) float32. */
+int sn_cvc(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
+           const float *mean6, float *out);
+/* nViewPair_SurfaceNet_fn (nets/SurfaceNet.py:365-382; call at main_reconstruct.py:145-146).
+ * X (n*n_vp, 6, s,s,s) float32 mean-subtracted; w (n, n_vp) float32 (NULL iff n_vp == 1);
+ * fused (n,1,s,s,s); unfused (n,n_vp,s,s,s) or NULL. */
+int sn_forward(sn_ctx *ctx, int n, int n_vp, const float *X, const float *w, float *fused, float *unfused);
+/* The loop body main_reconstruct.py:134-146 in one call: CVC warp -> mean subtraction -> CNN ->
+ * fusion, nothing but the cube parameters crossing PCIe. cvc_out (optional) receives the
+ * mean-subtracted CVC tensor the reference keeps for colour fusion (main_reconstruct.py:150). */
+int sn_cvc_forward(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
+                   const float *mean6, const float *w, float *fused, float *unfused, float *cvc_out);
+/* viewPair_relativeImpt_fn (nets/SurfaceNet.py:334-338; used at utils/viewPairSelection.py:77):
+ * features (n*n_vp, 258) float32 -> softmax weights (n, n_vp). */
+int sn_relative_weights(sn_ctx *ctx, int n, int n_vp, const float *features, float *weights);
+
+/* ---- hot path, device-resident (asynchronous on the context's stream) ------------------------- */
+void *sn_dev_alloc(sn_ctx *ctx, size_t bytes);
+int sn_dev_free(sn_ctx *ctx, void *p_dev);
+int sn_memcpy_h2d(sn_ctx *ctx, void *dst_dev, const void *src, size_t bytes);
+int sn_memcpy_d2h(sn_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
+/* Same as sn_cvc_forward with every array already in HBM. n*n_vp <= max_samples. mean6 is host. */
+int sn_cvc_forward_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
+                       const float *resol_dev, const float *mean6, const float *w_dev, float *fused_dev,
+                       float *unfused_dev, float *cvc_out_dev);
+int sn_cvc_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
+               const float *resol_dev, const float *mean6, float *out_dev);
+int sn_forward_dev(sn_ctx *ctx, int n, int n_vp, const float *X_dev, const float *w_dev, float *fused_dev,
+                   float *unfused_dev);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Per-kernel HIP-event timing on the context's stream. While enabled every kernel launch is
+ * bracketed by events; sn_profile_get drains them. idx enumerates kernel tags (layer names);
+ * returns 1 past the last. flops / bytes are the ALGORITHMIC work of the recorded launches. */
+int sn_profile_enable(sn_ctx *ctx, int on);
+int sn_profile_count(sn_ctx *ctx);
+int sn_profile_get(sn_ctx *ctx, int idx, char *name, int name_cap, double *ms_total, int64_t *launches,
+                   double *flops, double *bytes);
+int sn_profile_reset(sn_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURFACENET_HIP_H */

@@ -1,0 +1,53 @@
+"""Drop-in for the inference entry point of the reference's `nets/SurfaceNet.py`, executed on the MI355X.
+
+`SurfaceNet_inference(N_viewPairs4inference, model_file, layerNameList_2_load)` (nets/SurfaceNet.py:385-402)
+returns `(viewPair_relativeImpt_fn, nViewPair_SurfaceNet_fn)` with the calling conventions of the two compiled
+Theano functions (nets/SurfaceNet.py:337-338, 365-382):
+    viewPair_relativeImpt_fn(features (n*P,258) f32 [, n_samples_perGroup=P]) -> (n, P) f32 softmax weights
+    nViewPair_SurfaceNet_fn(X [, w][, n_samples_perGroup])  -> [fused (n,1,s,s,s) f32, unfused (n,N_vp,s,s,s) f32]
+X is float32 (n*N_vp, 6, s,s,s), mean-subtracted; w is float32 (n, N_vp). TypeError on dtype/ndim mismatch, as Theano.
+"""
+import numpy as np
+
+from . import runtime, weights
+
+
+def SurfaceNet_inference(N_viewPairs4inference, model_file, layerNameList_2_load=None, cube_D=None, param_values=None):
+    """model_file: the reference's `*.model` pickle. `param_values` (list of arrays in weight-file order) may be given
+    instead, e.g. weights.synthetic_param_values(seed). cube_D defaults to runtime.DEFAULT_CUBE_D (params.py:65)."""
+    values = param_values if param_values is not None else weights.load_lasagne_pickle(model_file)
+    cube_D = runtime.DEFAULT_CUBE_D if cube_D is None else cube_D
+    runtime.set_param_values(values)
+    N_vp = int(N_viewPairs4inference)
+
+    def viewPair_relativeImpt_fn(similFeature, n_samples_perGroup=N_vp):
+        f = np.asarray(similFeature)
+        if f.dtype != np.float32 or f.ndim != 2:
+            raise TypeError("similFeature must be a float32 matrix")
+        ctx = runtime.context_for(cube_D, n_samples=1)
+        return ctx.relative_weights(f, int(n_samples_perGroup))
+
+    def nViewPair_SurfaceNet_fn(X, *args, **kwargs):
+        n_per = int(kwargs.pop("n_samples_perGroup", N_vp))
+        if kwargs:
+            raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
+        if N_vp == 1:
+            if len(args) > 0:
+                raise TypeError("the N_viewPairs4inference == 1 function takes X only (nets/SurfaceNet.py:354-357)")
+            w = None
+            n_per = 1
+        else:
+            if len(args) < 1 or len(args) > 2:
+                raise TypeError("expected (X, similWeight[, n_samples_perGroup])")
+            w = args[0]
+            if len(args) == 2:
+                n_per = int(args[1])
+        if not isinstance(X, np.ndarray) or X.dtype != np.float32 or X.ndim != 5:
+            raise TypeError("X must be a float32 5-D ndarray")
+        ctx = runtime.context_for(cube_D, n_samples=X.shape[0])
+        fused, unfused = ctx.forward(X, w, n_vp=n_per, return_unfused=True)
+        if N_vp == 1:
+            return [fused, fused]      # both outputs are the same tensor in the reference (SurfaceNet.py:355-357)
+        return [fused, unfused]
+
+    return viewPair_relativeImpt_fn, nViewPair_SurfaceNet_fn

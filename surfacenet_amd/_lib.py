@@ -1,0 +1,104 @@
+"""ctypes binding of libsurfacenet_hip.so (include/surfacenet_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device is visible every
+entry point raises `SurfaceNetHipError` — the product path never routes through oracle/ or numpy.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsurfacenet_hip.so")
+
+# Every symbol include/surfacenet_hip.h declares (tests/test_abi.py checks the two lists agree).
+ABI_SYMBOLS = [
+    "sn_create", "sn_destroy", "sn_last_error", "sn_version", "sn_synchronize",
+    "sn_load_weights", "sn_set_images", "sn_set_cameras",
+    "sn_cvc", "sn_forward", "sn_cvc_forward", "sn_relative_weights",
+    "sn_dev_alloc", "sn_dev_free", "sn_memcpy_h2d", "sn_memcpy_d2h",
+    "sn_cvc_forward_dev", "sn_cvc_dev", "sn_forward_dev",
+    "sn_profile_enable", "sn_profile_count", "sn_profile_get", "sn_profile_reset",
+]
+
+
+class SurfaceNetHipError(RuntimeError):
+    pass
+
+
+class ParamDesc(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_int64), ("ndim", ctypes.c_int32), ("shape", ctypes.c_int32 * 5)]
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library (once). Raises SurfaceNetHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SurfaceNetHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C surfacenet_amd/csrc`). The MI355X path has no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise SurfaceNetHipError("cannot load %s: %s" % (LIB_PATH, e))
+    c_void_p, c_int, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    P = ctypes.POINTER
+    sig = {
+        "sn_create": (c_void_p, [c_int, c_int, c_int]),
+        "sn_destroy": (None, [c_void_p]),
+        "sn_last_error": (ctypes.c_char_p, []),
+        "sn_version": (c_int, []),
+        "sn_synchronize": (c_int, [c_void_p]),
+        "sn_load_weights": (c_int, [c_void_p, c_void_p, c_size_t, P(ParamDesc), c_int]),
+        "sn_set_images": (c_int, [c_void_p, c_int, P(c_void_p), P(c_int), P(c_int)]),
+        "sn_set_cameras": (c_int, [c_void_p, c_int, c_void_p]),
+        "sn_cvc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "sn_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "sn_cvc_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 8),
+        "sn_relative_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+        "sn_dev_alloc": (c_void_p, [c_void_p, c_size_t]),
+        "sn_dev_free": (c_int, [c_void_p, c_void_p]),
+        "sn_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+        "sn_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+        "sn_cvc_forward_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 8),
+        "sn_cvc_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5),
+        "sn_forward_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4),
+        "sn_profile_enable": (c_int, [c_void_p, c_int]),
+        "sn_profile_count": (c_int, [c_void_p]),
+        "sn_profile_get": (c_int, [c_void_p, c_int, ctypes.c_char_p, c_int, P(ctypes.c_double), P(ctypes.c_int64),
+                                   P(ctypes.c_double), P(ctypes.c_double)]),
+        "sn_profile_reset": (c_int, [c_void_p]),
+    }
+    assert sorted(sig) == sorted(ABI_SYMBOLS)
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sn_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != 0:
+        raise SurfaceNetHipError("libsurfacenet_hip: %s (status %d)" % (last_error(), rc))
+
+
+def ptr(a):
+    """Host pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def as_c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)

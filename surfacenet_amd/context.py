@@ -1,0 +1,178 @@
+"""`Context`: one GPU's SurfaceNet inference state (images, cameras, weights, workspace) over the C ABI."""
+import ctypes
+
+import numpy as np
+
+from . import _lib, weights as _weights
+
+MEAN_CVC_RGBRGB = np.asarray([123.68, 116.779, 103.939, 123.68, 116.779, 103.939]).astype(np.float32)  # params.py:129
+
+
+class Context(object):
+    def __init__(self, cube_D=32, max_samples=64, device=0):
+        self._lib = _lib.load()
+        self.cube_D, self.max_samples, self.device = int(cube_D), int(max_samples), int(device)
+        self._h = self._lib.sn_create(self.device, self.cube_D, self.max_samples)
+        if not self._h:
+            raise _lib.SurfaceNetHipError("sn_create failed: %s" % _lib.last_error())
+        self.n_views = 0
+        self._keep = {}
+
+    # ---- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        _lib.check(self._lib.sn_synchronize(self._h))
+
+    # ---- setup ------------------------------------------------------------------------------------
+    def load_param_values(self, values):
+        """values: the reference weight file's list of arrays (98 or 105, weights.PARAM_LAYOUT order)."""
+        blob, descs = _weights.to_blob(values)
+        _lib.check(self._lib.sn_load_weights(self._h, _lib.ptr(blob), blob.size, descs, len(values)))
+
+    def set_images(self, models_img):
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in models_img]
+        for im in imgs:
+            if im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError("images must be (H, W, 3) uint8 RGB, got %s" % (im.shape,))
+        V = len(imgs)
+        ptrs = (ctypes.c_void_p * V)(*[im.ctypes.data for im in imgs])
+        H = (ctypes.c_int * V)(*[im.shape[0] for im in imgs])
+        W = (ctypes.c_int * V)(*[im.shape[1] for im in imgs])
+        _lib.check(self._lib.sn_set_images(self._h, V, ptrs, H, W))
+        self.n_views = V
+
+    def set_cameras(self, cameraPOs):
+        P = np.ascontiguousarray(cameraPOs, dtype=np.float64)
+        if P.ndim != 3 or P.shape[1:] != (3, 4):
+            raise ValueError("cameraPOs must have shape (V, 3, 4), got %s" % (P.shape,))
+        _lib.check(self._lib.sn_set_cameras(self._h, P.shape[0], _lib.ptr(P)))
+
+    # ---- hot path, host arrays --------------------------------------------------------------------
+    def _batch_args(self, selected_viewPairs, xyz, resol):
+        pairs = np.ascontiguousarray(selected_viewPairs, dtype=np.int64)
+        if pairs.ndim != 3 or pairs.shape[2] != 2:
+            raise ValueError("selected_viewPairs must have shape (N_cubes, N_viewPairs, 2), got %s" % (pairs.shape,))
+        n, n_vp = pairs.shape[:2]
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(n, 3)
+        resol = np.ascontiguousarray(resol, dtype=np.float32).reshape(n)
+        return pairs, xyz, resol, n, n_vp
+
+    def cvc(self, selected_viewPairs, xyz, resol, mean=None):
+        pairs, xyz, resol, n, n_vp = self._batch_args(selected_viewPairs, xyz, resol)
+        s = self.cube_D
+        out = np.empty((n * n_vp, 6, s, s, s), dtype=np.float32)
+        m = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32).reshape(6)
+        _lib.check(self._lib.sn_cvc(self._h, n, n_vp, _lib.ptr(pairs), _lib.ptr(xyz), _lib.ptr(resol), _lib.ptr(m), _lib.ptr(out)))
+        return out
+
+    def forward(self, X, w=None, n_vp=1, return_unfused=True):
+        s = self.cube_D
+        if not isinstance(X, np.ndarray) or X.dtype != np.float32:
+            raise TypeError("X must be a float32 ndarray (the reference's Theano function rejects other dtypes)")
+        if X.ndim != 5 or X.shape[1:] != (6, s, s, s):
+            raise TypeError("X must have shape (N*n_vp, 6, %d, %d, %d), got %s" % (s, s, s, X.shape))
+        if X.shape[0] % n_vp:
+            raise ValueError("X.shape[0]=%d is not a multiple of n_vp=%d" % (X.shape[0], n_vp))
+        n = X.shape[0] // n_vp
+        X = np.ascontiguousarray(X)
+        if n_vp > 1:
+            if not isinstance(w, np.ndarray) or w.dtype != np.float32 or w.shape != (n, n_vp):
+                raise TypeError("w must be a float32 ndarray of shape (%d, %d)" % (n, n_vp))
+            w = np.ascontiguousarray(w)
+        else:
+            w = None
+        fused = np.empty((n, 1, s, s, s), dtype=np.float32)
+        unfused = np.empty((n, n_vp, s, s, s), dtype=np.float32) if return_unfused else None
+        _lib.check(self._lib.sn_forward(self._h, n, n_vp, _lib.ptr(X), _lib.ptr(w), _lib.ptr(fused), _lib.ptr(unfused)))
+        return fused, unfused
+
+    def cvc_forward(self, selected_viewPairs, xyz, resol, w=None, mean=MEAN_CVC_RGBRGB, return_unfused=True, return_cvc=False):
+        pairs, xyz, resol, n, n_vp = self._batch_args(selected_viewPairs, xyz, resol)
+        s = self.cube_D
+        if n_vp > 1:
+            w = np.ascontiguousarray(w, dtype=np.float32).reshape(n, n_vp)
+        else:
+            w = None
+        m = np.ascontiguousarray(mean, dtype=np.float32).reshape(6)
+        fused = np.empty((n, 1, s, s, s), dtype=np.float32)
+        unfused = np.empty((n, n_vp, s, s, s), dtype=np.float32) if return_unfused else None
+        cvc = np.empty((n * n_vp, 6, s, s, s), dtype=np.float32) if return_cvc else None
+        _lib.check(self._lib.sn_cvc_forward(self._h, n, n_vp, _lib.ptr(pairs), _lib.ptr(xyz), _lib.ptr(resol), _lib.ptr(m),
+                                            _lib.ptr(w), _lib.ptr(fused), _lib.ptr(unfused), _lib.ptr(cvc)))
+        return fused, unfused, cvc
+
+    def relative_weights(self, features, n_vp):
+        f = np.ascontiguousarray(features, dtype=np.float32)
+        if f.ndim != 2 or f.shape[1] != _weights.D_VIEWPAIR_FEATURE or f.shape[0] % n_vp:
+            raise TypeError("features must have shape (n*n_vp, %d)" % _weights.D_VIEWPAIR_FEATURE)
+        n = f.shape[0] // n_vp
+        out = np.empty((n, n_vp), dtype=np.float32)
+        _lib.check(self._lib.sn_relative_weights(self._h, n, n_vp, _lib.ptr(f), _lib.ptr(out)))
+        return out
+
+    # ---- hot path, device-resident ------------------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = self._lib.sn_dev_alloc(self._h, int(nbytes))
+        if not p:
+            raise _lib.SurfaceNetHipError("sn_dev_alloc failed: %s" % _lib.last_error())
+        return p
+
+    def dev_free(self, p):
+        _lib.check(self._lib.sn_dev_free(self._h, p))
+
+    def h2d(self, dst_dev, arr):
+        arr = np.ascontiguousarray(arr)
+        _lib.check(self._lib.sn_memcpy_h2d(self._h, dst_dev, _lib.ptr(arr), arr.nbytes))
+
+    def d2h(self, arr, src_dev):
+        assert arr.flags["C_CONTIGUOUS"]
+        _lib.check(self._lib.sn_memcpy_d2h(self._h, _lib.ptr(arr), src_dev, arr.nbytes))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.dev_alloc(max(arr.nbytes, 16))
+        self.h2d(p, arr)
+        return p
+
+    def cvc_forward_dev(self, n, n_vp, pairs_dev, xyz_dev, resol_dev, w_dev, fused_dev, unfused_dev=None, cvc_out_dev=None,
+                        mean=MEAN_CVC_RGBRGB):
+        m = np.ascontiguousarray(mean, dtype=np.float32).reshape(6)
+        _lib.check(self._lib.sn_cvc_forward_dev(self._h, n, n_vp, pairs_dev, xyz_dev, resol_dev, _lib.ptr(m), w_dev, fused_dev,
+                                                unfused_dev, cvc_out_dev))
+
+    # ---- measurement --------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _lib.check(self._lib.sn_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        _lib.check(self._lib.sn_profile_reset(self._h))
+
+    def profile(self):
+        """-> {kernel tag: dict(ms, launches, flops, bytes)} accumulated since the last reset."""
+        n = self._lib.sn_profile_count(self._h)
+        if n < 0:
+            _lib.check(n)
+        out = {}
+        name = ctypes.create_string_buffer(64)
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        cnt = ctypes.c_int64()
+        for i in range(n):
+            _lib.check(self._lib.sn_profile_get(self._h, i, name, 64, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl), ctypes.byref(by)))
+            out[name.value.decode()] = dict(ms=ms.value, launches=cnt.value, flops=fl.value, bytes=by.value)
+        return out

@@ -1,0 +1,226 @@
+// conv3d_mfma.h — implicit-GEMM 3-D convolution on the CDNA4 matrix cores (gfx950 only).
+//
+// Replaces, for the MI355X path, what the reference obtains from cuDNN through Lasagne:
+//   Conv3DDNNLayer 3x3x3 / 1x1x1 'same' cross-correlation   (nets/SurfaceNet.py:33-74)
+//   DilatedConv3DLayer via GpuDnnConv3dGradW, dilation 2     (nets/layers.py:200-253)
+//   batch_norm(...) at deterministic=True folded to y = act(conv*scale + shift)
+//   merge_conv3 (1x1x1, 100 -> 1, BN, sigmoid) fused as a second epilogue (nets/SurfaceNet.py:74)
+//
+// Data layout (ours, not the reference's NCDHW): activations are channels-last fp16
+//   act[b][x][y][z][c], c padded to a multiple of 8, so one voxel's 8-channel group is one 16-byte
+//   vector = exactly one lane's share of a v_mfma_f32_16x16x32_f16 B operand.
+// GEMM view: D[cout][voxel] += W[cout][k] * X[k][voxel], k = (tap, cin) in 8-channel groups.
+//   A operand = weights, pre-packed on the host in fragment order (lane l: cout = l&15,
+//               k = (l>>4)*8 + j) and streamed global -> LDS with global_load_lds_dwordx4;
+//   B operand = activations of a (TX+2R)x(TY+2R)x(TZ+2R) halo tile staged once per channel slab
+//               in LDS and re-read for every one of the 27 taps;
+//   D         = lane l, reg r: voxel = l&15, cout = (l>>4)*4 + r  -> 4 consecutive channels per lane,
+//               stored as one 8-byte fp16x4.
+// Work decomposition: one 256-thread workgroup = 4 waves = TX x 8 x 8 output voxels x (NF*16)
+//   output channels; wave w owns x-slices [w*XS, w*XS+XS); every wave holds all NF channel
+//   fragments, so no activation is re-read for another channel block and the 1x1x1 reduction of
+//   merge_conv3 stays inside a wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sn {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxSlab = 48;
+
+struct ConvArgs {
+    const _Float16 *in;   // [B][D][D][D][in_cs]
+    _Float16 *out;        // [B][D][D][D][out_cs] (+ out_coff)
+    float *out_f32;       // EPI_FINAL: [B][D][D][D]
+    const _Float16 *wpack;
+    const float *scale;   // [nsplit*NF*16]
+    const float *shift;
+    const float *w3;      // EPI_FINAL: [NF*16] fp32 weights of the fused 1x1x1 conv
+    float scale3, shift3;
+    long long wsplit_stride;  // halfs between channel splits in wpack
+    int in_cs, out_cs, out_coff, out_cp;
+    int D, tiles_x, tiles_y, tiles_z;
+    int act;              // 0 relu, 1 sigmoid
+    int nslab;
+    unsigned char slab_c8[kMaxSlab];  // 8-channel groups per slab
+};
+
+enum { EPI_STORE = 0, EPI_FINAL = 1 };
+
+__device__ __forceinline__ float sn_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <int KS, int DIL, int MF, int NF, int EPI>
+struct ConvCfg {
+    static constexpr int R = (KS / 2) * DIL;
+    static constexpr int XS = MF / 4;  // x-slices per wave
+    static constexpr int TX = 4 * XS, TY = 8, TZ = 8;
+    static constexpr int HX = TX + 2 * R, HY = TY + 2 * R, HZ = TZ + 2 * R;
+    static constexpr int HVOX = HX * HY * HZ;
+    static constexpr int CS8MAX = (KS == 1) ? 10 : 4;      // 8-channel groups per slab
+    static constexpr int VS = CS8MAX * 16 + 16;            // LDS bytes per halo voxel (+16: bank spread)
+    static constexpr int PCH = (NF >= 7) ? 2 : (NF >= 4 ? 3 : (NF == 2 ? 8 : 16));  // chunks per weight piece
+    static constexpr int WBUF = PCH * NF * 1024;
+    static constexpr int NTAP = KS * KS * KS;
+    static constexpr int KOFF_N = NTAP * CS8MAX + 4;
+    static constexpr int XT_BYTES = HVOX * VS;
+    static constexpr int LDS_BYTES = XT_BYTES + 2 * WBUF + KOFF_N * 4;
+};
+
+template <int KS, int DIL, int MF, int NF, int EPI>
+__global__ void __launch_bounds__(256) conv3d_f16_mfma(ConvArgs a)
+{
+    using C = ConvCfg<KS, DIL, MF, NF, EPI>;
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
+    char *xt = lds;
+    char *wb = lds + C::XT_BYTES;
+    int *koff = reinterpret_cast<int *>(lds + C::XT_BYTES + 2 * C::WBUF);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v = lane & 15, kq = lane >> 4;
+
+    int t = blockIdx.x;
+    const int tz = t % a.tiles_z; t /= a.tiles_z;
+    const int ty = t % a.tiles_y; t /= a.tiles_y;
+    const int tx = t % a.tiles_x;
+    const int b = t / a.tiles_x;
+    const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
+    const int D = a.D;
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int xbase[MF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const int hx = wave * C::XS + (m >> 2), hy = 2 * (m & 3) + (v >> 3), hz = v & 7;
+        xbase[m] = ((hx * C::HY + hy) * C::HZ + hz) * C::VS;
+    }
+
+    const char *wsrc = reinterpret_cast<const char *>(a.wpack + (size_t)blockIdx.y * a.wsplit_stride);
+    const _Float16 *in_b = a.in + (size_t)b * D * D * D * a.in_cs;
+    int c0 = 0;
+
+    for (int slab = 0; slab < a.nslab; ++slab) {
+        const int c8n = a.slab_c8[slab];
+        const int G = C::NTAP * c8n;
+        const int nchunk = (G + 3) >> 2;
+        const int npiece = (nchunk + C::PCH - 1) / C::PCH;
+
+        __syncthreads();  // all reads of the previous slab's tile / table / weight buffers are done
+
+        for (int g = tid; g < nchunk * 4; g += 256) {
+            int o = 0;
+            if (g < G) {
+                const int tap = g / c8n, c8 = g - tap * c8n;
+                const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
+                o = ((dx * DIL * C::HY + dy * DIL) * C::HZ + dz * DIL) * C::VS + c8 * 16;
+            }
+            koff[g] = o;
+        }
+        // halo tile of this channel slab: global -> registers -> LDS, zero outside the volume (= 'same' padding)
+        for (int item = tid; item < C::HVOX * c8n; item += 256) {
+            const int hv = item / c8n, c8 = item - hv * c8n;
+            const int hz = hv % C::HZ, hy = (hv / C::HZ) % C::HY, hx = hv / (C::HZ * C::HY);
+            const int gx = x0 - C::R + hx, gy = y0 - C::R + hy, gz = z0 - C::R + hz;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D)
+                val = *reinterpret_cast<const uint4 *>(in_b + ((size_t)(gx * D + gy) * D + gz) * a.in_cs + (c0 + c8) * 8);
+            *reinterpret_cast<uint4 *>(xt + hv * C::VS + c8 * 16) = val;
+        }
+        // weight piece 0 -> buffer 0 (LDS-DMA: lane-linear, one 1 KiB fragment per wave-instruction)
+        {
+            const int cnt = (nchunk < C::PCH ? nchunk : C::PCH) * NF;
+            for (int i = wave; i < cnt; i += 4)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(wsrc + (size_t)i * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void *)(wb + i * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        for (int p = 0; p < npiece; ++p) {
+            const int ch0 = p * C::PCH;
+            if (p + 1 < npiece) {
+                const int rem = nchunk - (ch0 + C::PCH);
+                const int cnt = (rem < C::PCH ? rem : C::PCH) * NF;
+                const char *src = wsrc + (size_t)(ch0 + C::PCH) * NF * 1024;
+                char *dst = wb + ((p + 1) & 1) * C::WBUF;
+                for (int i = wave; i < cnt; i += 4)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + (size_t)i * 1024 + lane * 16),
+                        (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
+            }
+            const char *wcur = wb + (p & 1) * C::WBUF;
+#pragma unroll
+            for (int cc = 0; cc < C::PCH; ++cc) {
+                const int ch = ch0 + cc;
+                if (ch < nchunk) {
+                    const int ko = koff[ch * 4 + kq];
+                    half8 xf[MF];
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) xf[m] = *reinterpret_cast<const half8 *>(xt + xbase[m] + ko);
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) {
+                        const half8 wf = *reinterpret_cast<const half8 *>(wcur + ((cc * NF + n) * 64 + lane) * 16);
+#pragma unroll
+                        for (int m = 0; m < MF; ++m)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[m], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        wsrc += (size_t)nchunk * NF * 1024;
+        c0 += c8n;
+    }
+
+    // ---- epilogue: folded BN affine + activation ------------------------------------------------
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
+        const bool valid = gx < D && gy < D && gz < D;
+        const size_t vox = ((size_t)(b * D + gx) * D + gy) * D + gz;
+        if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
+                if (valid && nl < a.out_cp) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                    half4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float y = acc[m][n][r] * sc[r] + sh[r];
+                        y = a.act == 0 ? fmaxf(y, 0.f) : sn_sigmoid(y);
+                        h[r] = (_Float16)y;
+                    }
+                    *reinterpret_cast<half4 *>(a.out + vox * a.out_cs + a.out_coff + nl) = h;
+                }
+            }
+        } else {
+            float part = 0.f;
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                const int nl = n * 16 + kq * 4;
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.w3 + nl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(part * a.scale3 + a.shift3);
+        }
+    }
+}
+
+}  // namespace sn

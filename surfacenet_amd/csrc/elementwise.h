@@ -1,0 +1,145 @@
+// elementwise.h — the HBM-bound glue ops of the SurfaceNet graph on channels-last fp16 tensors.
+//   maxpool2_kernel      Pool3DDNNLayer((2,2,2), stride=2)                 nets/SurfaceNet.py:37,46
+//   upsample_cat_kernel  Bilinear_3DInterpolation (zero-insert + fixed k^3 conv, closed form of
+//                        SURVEY App. D) written straight into its channel block of the
+//                        ConcatLayer buffer                                nets/layers.py:363-390, SurfaceNet.py:71
+//   fuse_kernel          ChannelPool_weightedAverage over the view pairs   nets/layers.py:325-336
+//   relw_*               the relative-weight MLP + grouped softmax         nets/SurfaceNet.py:84-100
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sn {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// in [B][D][D][D][C] -> out [B][D/2][D/2][D/2][C]; one thread = one output voxel x 8 channels.
+__global__ void __launch_bounds__(256) maxpool2_kernel(const _Float16 *in, _Float16 *out, int D, int C, long long total)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c8n = C >> 3, Do = D >> 1;
+    const int c8 = (int)(idx % c8n);
+    long long t = idx / c8n;
+    const int z = (int)(t % Do); t /= Do;
+    const int y = (int)(t % Do); t /= Do;
+    const int x = (int)(t % Do);
+    const long long b = t / Do;
+    const _Float16 *p = in + ((((b * D + 2 * x) * D + 2 * y) * D + 2 * z) * (long long)C) + c8 * 8;
+    h8 m = *reinterpret_cast<const h8 *>(p);
+#pragma unroll
+    for (int o = 1; o < 8; ++o) {
+        const h8 q = *reinterpret_cast<const h8 *>(p + ((long long)((o >> 2) * D + ((o >> 1) & 1)) * D + (o & 1)) * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = q[e] > m[e] ? q[e] : m[e];
+    }
+    *reinterpret_cast<h8 *>(out + idx * 8) = m;
+}
+
+// Per-axis operator of the "bilinear" upsampler: output index o = F*m + ph reads
+// in[m]*wa + in[m+1]*wb with in[m+1] = 0 past the end.
+template <int F>
+__device__ __forceinline__ void up_axis(int o, int n_in, int &m, float &wa, float &wb)
+{
+    m = o / F;
+    const int ph = o - m * F;
+    if (F == 2) {
+        wa = ph == 0 ? 1.f : 0.5f;
+        wb = ph == 0 ? 0.f : 0.5f;
+    } else {
+        const float third = 1.0f / 3.0f, two3 = 2.0f / 3.0f;
+        wa = ph == 0 ? 1.f : (ph == 1 ? two3 : (ph == 2 ? third : 0.f));
+        wb = ph == 0 ? 0.f : (ph == 1 ? 0.f : (ph == 2 ? third : two3));
+    }
+    if (m + 1 >= n_in) wb = 0.f;
+}
+
+// in [B][Di][Di][Di][16] -> cat [B][Do][Do][Do][cat_cs] channels [coff, coff+16), Do = F*Di.
+// One thread = one output voxel x 8 channels.
+template <int F>
+__global__ void __launch_bounds__(256) upsample_cat_kernel(const _Float16 *in, _Float16 *cat, int Di, int cat_cs, int coff,
+                                                           long long total)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int Do = Di * F;
+    const int c8 = (int)(idx & 1);
+    long long t = idx >> 1;
+    const int z = (int)(t % Do); t /= Do;
+    const int y = (int)(t % Do); t /= Do;
+    const int x = (int)(t % Do);
+    const long long b = t / Do;
+    int mx, my, mz;
+    float ax, bx, ay, by, az, bz;
+    up_axis<F>(x, Di, mx, ax, bx);
+    up_axis<F>(y, Di, my, ay, by);
+    up_axis<F>(z, Di, mz, az, bz);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int dx = o >> 2, dy = (o >> 1) & 1, dz = o & 1;
+        const float w = (dx ? bx : ax) * (dy ? by : ay) * (dz ? bz : az);
+        if (w != 0.f) {
+            const h8 q = *reinterpret_cast<const h8 *>(in + ((((b * Di + mx + dx) * Di + my + dy) * Di + mz + dz) * 16LL) + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += w * (float)q[e];
+        }
+    }
+    h8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (_Float16)acc[e];
+    *reinterpret_cast<h8 *>(cat + ((((b * Do + x) * Do + y) * Do + z) * (long long)cat_cs) + coff + c8 * 8) = r;
+}
+
+// unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.
+__global__ void __launch_bounds__(256) fuse_kernel(const float *unfused, const float *w, float *fused, int n_vp, int s3, long long total)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long cube = idx / s3;
+    const int vox = (int)(idx - cube * s3);
+    const float *u = unfused + cube * n_vp * (long long)s3 + vox;
+    if (w == nullptr) { fused[idx] = u[0]; return; }
+    float wsum = 0.f;
+    for (int p = 0; p < n_vp; ++p) wsum += w[cube * n_vp + p];
+    float acc = 0.f;
+    for (int p = 0; p < n_vp; ++p) acc += u[(long long)p * s3] * (w[cube * n_vp + p] / wsum);
+    fused[idx] = acc;
+}
+
+// Relative-weight MLP: one block (128 threads) per feature row. W1 (258,100) row-major fp32.
+__global__ void __launch_bounds__(128) relw_mlp_kernel(const float *feat, const float *W1, const float *scale1, const float *shift1,
+                                                       const float *w2, float b2, float *z, int d_in, int n_hidden)
+{
+    __shared__ float red[128];
+    const int row = blockIdx.x, j = threadIdx.x;
+    float hv = 0.f;
+    if (j < n_hidden) {
+        const float *f = feat + (size_t)row * d_in;
+        float acc = 0.f;
+        for (int k = 0; k < d_in; ++k) acc += f[k] * W1[(size_t)k * n_hidden + j];
+        hv = 1.0f / (1.0f + expf(-(acc * scale1[j] + shift1[j]))) * w2[j];
+    }
+    red[j] = hv;
+    __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) {
+        if (j < st) red[j] += red[j + st];
+        __syncthreads();
+    }
+    if (j == 0) z[row] = red[0] + b2;
+}
+
+__global__ void relw_softmax_kernel(const float *z, float *out, int n, int n_vp)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    float mx = -3.0e38f;
+    for (int p = 0; p < n_vp; ++p) mx = fmaxf(mx, z[(size_t)g * n_vp + p]);
+    float sum = 0.f;
+    for (int p = 0; p < n_vp; ++p) sum += expf(z[(size_t)g * n_vp + p] - mx);
+    for (int p = 0; p < n_vp; ++p) out[(size_t)g * n_vp + p] = expf(z[(size_t)g * n_vp + p] - mx) / sum;
+}
+
+}  // namespace sn

@@ -1,0 +1,828 @@
+// sn_api.hip — C ABI (include/surfacenet_hip.h) over the gfx950 kernels: context, weight folding and
+// MFMA-fragment packing, activation workspace, the layer schedule of the SurfaceNet graph
+// (nets/SurfaceNet.py:18-76), and HIP-event profiling. Build: surfacenet_amd/csrc/Makefile.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/surfacenet_hip.h"
+#include "conv3d_mfma.h"
+#include "cvc_warp.h"
+#include "elementwise.h"
+
+using namespace sn;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(SN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// network description (restated from nets/SurfaceNet.py:18-76; order = weight-file order, App. B)
+// ------------------------------------------------------------------------------------------------
+enum Kind { K_CONV3, K_CONV1, K_DIL3, K_DIL1, K_UP };
+struct LayerSpec { const char *name; Kind kind; int cin, cout, act; };  // K_UP: cin = kernel size, cout = factor
+static const LayerSpec kSpecs[] = {
+    {"conv1_1", K_CONV3, 6, 32, 0},    {"conv1_2", K_CONV3, 32, 32, 0},   {"conv1_3", K_CONV3, 32, 32, 0},
+    {"side_op1", K_CONV1, 32, 16, 1},
+    {"conv2_1", K_CONV3, 32, 80, 0},   {"conv2_2", K_CONV3, 80, 80, 0},   {"conv2_3", K_CONV3, 80, 80, 0},
+    {"side_op2", K_CONV1, 80, 16, 1},  {"side_op2_deconv", K_UP, 3, 2, 0},
+    {"conv3_1", K_CONV3, 80, 160, 0},  {"conv3_2", K_CONV3, 160, 160, 0}, {"conv3_3", K_CONV3, 160, 160, 0},
+    {"side_op3", K_CONV1, 160, 16, 1}, {"side_op3_deconv", K_UP, 5, 4, 0},
+    {"conv4_1", K_DIL3, 160, 300, 0},  {"conv4_2", K_DIL3, 300, 300, 0},  {"conv4_3", K_DIL3, 300, 300, 0},
+    {"side_op4", K_DIL1, 300, 16, 1},  {"side_op4_deconv", K_UP, 5, 4, 0},
+    {"merge_conv_a", K_CONV3, 64, 100, 0}, {"merge_conv_b", K_CONV3, 100, 100, 0}, {"merge_conv3", K_CONV1, 100, 1, 1},
+};
+static constexpr int kNumSpecs = sizeof(kSpecs) / sizeof(kSpecs[0]);
+static constexpr int kNetParams = 98, kAllParams = 105, kDFeature = 258, kHidden = 100;
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// A conv layer prepared for conv3d_f16_mfma: packed fp16 weight fragments + folded BN.
+struct PackedConv {
+    std::string name;
+    int cin = 0, cout = 0, ks = 1, dil = 1, act = 0;
+    int cin_p = 0;             // input channels padded to 8
+    int nf = 0, nsplit = 1;    // 16-channel fragments per workgroup, workgroup columns
+    int cs8max = 4;
+    std::vector<unsigned char> slab_c8;
+    long long wsplit_stride = 0;   // halfs
+    _Float16 *wpack = nullptr;     // device
+    float *scale = nullptr, *shift = nullptr;  // device, nsplit*nf*16
+    double macs_per_voxel = 0;
+};
+
+struct ProfRec { int tag; hipEvent_t e0, e1; double flops, bytes; };
+struct ProfStat { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
+
+struct sn_ctx {
+    int device = 0, s = 32, max_samples = 0;
+    hipStream_t stream = nullptr;
+    // images / cameras
+    int V_img = 0, V_cam = 0;
+    uint8_t *img_base = nullptr; long long *img_off = nullptr; int *img_h = nullptr, *img_w = nullptr;
+    double *cams = nullptr;
+    // weights
+    bool have_weights = false, have_relw = false;
+    std::map<std::string, PackedConv> conv;
+    float *w3 = nullptr; float scale3 = 0, shift3 = 0;
+    float *relw_W1 = nullptr, *relw_scale = nullptr, *relw_shift = nullptr, *relw_w2 = nullptr; float relw_b2 = 0;
+    // activation workspace (channels-last fp16)
+    _Float16 *x0 = nullptr, *a1 = nullptr, *b1 = nullptr, *cat = nullptr, *p1 = nullptr, *a2 = nullptr, *b2 = nullptr,
+             *p2 = nullptr, *a3 = nullptr, *b3 = nullptr, *a4 = nullptr, *b4 = nullptr, *s2 = nullptr, *s3 = nullptr,
+             *s4 = nullptr, *ma = nullptr;
+    float *unf_ws = nullptr;      // [max_samples][s^3]
+    // batch parameter staging
+    int64_t *d_pairs = nullptr; float *d_xyz = nullptr, *d_resol = nullptr, *d_w = nullptr;
+    // host-API staging
+    float *d_X = nullptr;         // [max_samples][6][s^3] fp32 NCDHW
+    float *d_fused = nullptr;     // [max_samples][s^3]
+    std::vector<void *> owned;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<ProfStat> prof_stats;
+    std::map<std::string, int> prof_tags;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+template <typename T>
+static int dev_alloc(sn_ctx *c, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(SN_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    c->owned.push_back(q);
+    *p = static_cast<T *>(q);
+    return SN_OK;
+}
+
+static int dev_free_owned(sn_ctx *c, void *p)
+{
+    if (!p) return SN_OK;
+    auto it = std::find(c->owned.begin(), c->owned.end(), p);
+    if (it != c->owned.end()) c->owned.erase(it);
+    HIPCHK(hipFree(p));
+    return SN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling: every launch goes through prof_begin / prof_end
+// ------------------------------------------------------------------------------------------------
+static hipEvent_t get_event(sn_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    sn_ctx *c; ProfRec r; bool on;
+    ProfScope(sn_ctx *ctx, const std::string &tag, double flops, double bytes) : c(ctx), on(ctx->prof_on)
+    {
+        if (!on) return;
+        auto it = c->prof_tags.find(tag);
+        int id;
+        if (it == c->prof_tags.end()) {
+            id = (int)c->prof_stats.size();
+            c->prof_tags[tag] = id;
+            ProfStat st; st.name = tag;
+            c->prof_stats.push_back(st);
+        } else id = it->second;
+        r.tag = id; r.flops = flops; r.bytes = bytes;
+        r.e0 = get_event(c); r.e1 = get_event(c);
+        (void)hipEventRecord(r.e0, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, c->stream);
+        c->prof_recs.push_back(r);
+    }
+};
+
+static int prof_drain(sn_ctx *c)
+{
+    if (c->prof_recs.empty()) return SN_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof_recs) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        ProfStat &st = c->prof_stats[r.tag];
+        st.ms += ms; st.launches += 1; st.flops += r.flops; st.bytes += r.bytes;
+        c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1);
+    }
+    c->prof_recs.clear();
+    return SN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight preparation
+// ------------------------------------------------------------------------------------------------
+// W is given as (cout, cin, k,k,k) row-major fp32 (dilated layers are transposed by the caller).
+static int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const float *gamma, const float *mean,
+                     const float *inv_std, int nf, int nsplit, int cs8max)
+{
+    L.nf = nf; L.nsplit = nsplit; L.cs8max = cs8max;
+    L.cin_p = round_up(L.cin, 8);
+    const int ntap = L.ks * L.ks * L.ks;
+    const int c8_total = L.cin_p / 8;
+    L.slab_c8.clear();
+    for (int left = c8_total; left > 0; left -= cs8max) L.slab_c8.push_back((unsigned char)std::min(left, cs8max));
+    if ((int)L.slab_c8.size() > kMaxSlab) return fail(SN_ERR_ARG, "%s: too many channel slabs", L.name.c_str());
+    long long chunks = 0;
+    for (unsigned char c8n : L.slab_c8) chunks += (ntap * c8n + 3) / 4;
+    L.wsplit_stride = chunks * nf * 512;
+    std::vector<_Float16> h((size_t)L.wsplit_stride * nsplit, (_Float16)0.f);
+    for (int ns = 0; ns < nsplit; ++ns) {
+        _Float16 *dst = h.data() + (size_t)ns * L.wsplit_stride;
+        int c8_0 = 0;
+        for (unsigned char c8n : L.slab_c8) {
+            const int G = ntap * c8n, nchunk = (G + 3) / 4;
+            for (int ch = 0; ch < nchunk; ++ch)
+                for (int f = 0; f < nf; ++f)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int o = (ns * nf + f) * 16 + (lane & 15);
+                        const int g = 4 * ch + (lane >> 4);
+                        _Float16 *d8 = dst + (((size_t)ch * nf + f) * 64 + lane) * 8;
+                        if (g >= G || o >= L.cout) continue;
+                        const int tap = g / c8n, c8 = g % c8n;
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = (c8_0 + c8) * 8 + j;
+                            if (ci < L.cin) d8[j] = (_Float16)W[((size_t)o * L.cin + ci) * ntap + tap];
+                        }
+                    }
+            dst += (size_t)nchunk * nf * 512;
+            c8_0 += c8n;
+        }
+    }
+    std::vector<float> sc((size_t)nsplit * nf * 16 + 16, 0.f), sh((size_t)nsplit * nf * 16 + 16, 0.f);
+    for (int o = 0; o < L.cout; ++o) {
+        const float s = gamma[o] * inv_std[o];   // Lasagne BatchNormLayer, deterministic=True
+        sc[o] = s;
+        sh[o] = beta[o] - mean[o] * s;
+    }
+    int rc;
+    if ((rc = dev_alloc(c, &L.wpack, h.size() + 8192)) != SN_OK) return rc;
+    if ((rc = dev_alloc(c, &L.scale, sc.size())) != SN_OK) return rc;
+    if ((rc = dev_alloc(c, &L.shift, sh.size())) != SN_OK) return rc;
+    HIPCHK(hipMemcpy(L.wpack, h.data(), h.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(L.scale, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(L.shift, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+    L.macs_per_voxel = (double)L.cin * L.cout * ntap;
+    return SN_OK;
+}
+
+static bool shape_is(const sn_param_desc &d, std::initializer_list<int> s)
+{
+    if (d.ndim != (int)s.size()) return false;
+    int i = 0;
+    for (int v : s) if (d.shape[i++] != v) return false;
+    return true;
+}
+
+struct TileChoice { int nf, nsplit, cs8max; };
+static TileChoice tile_for(const LayerSpec &sp)
+{
+    if (sp.kind == K_CONV1 || sp.kind == K_DIL1) return {1, 1, 10};
+    if (sp.cout == 32) return {2, 1, 4};
+    if (sp.cout == 80) return {5, 1, 4};
+    if (sp.cout == 160) return {10, 1, 4};
+    if (sp.cout == 300) return {10, 2, 4};
+    return {7, 1, 4};  // cout 100
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+template <int KS, int DIL, int MF, int NF, int EPI>
+static int launch_conv(sn_ctx *c, const PackedConv &L, const _Float16 *in, int in_cs, _Float16 *out, int out_cs,
+                       int out_coff, int out_cp, float *out_f32, int B, int D)
+{
+    using C = ConvCfg<KS, DIL, MF, NF, EPI>;
+    if (L.nf != NF || L.ks != KS || L.dil != DIL || L.cs8max != C::CS8MAX)
+        return fail(SN_ERR_STATE, "%s: packed for a different kernel configuration", L.name.c_str());
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = in; a.out = out; a.out_f32 = out_f32; a.wpack = L.wpack; a.scale = L.scale; a.shift = L.shift;
+    a.w3 = c->w3; a.scale3 = c->scale3; a.shift3 = c->shift3;
+    a.wsplit_stride = L.wsplit_stride;
+    a.in_cs = in_cs; a.out_cs = out_cs; a.out_coff = out_coff; a.out_cp = out_cp;
+    a.D = D;
+    a.tiles_x = (D + C::TX - 1) / C::TX; a.tiles_y = (D + C::TY - 1) / C::TY; a.tiles_z = (D + C::TZ - 1) / C::TZ;
+    a.act = L.act;
+    a.nslab = (int)L.slab_c8.size();
+    for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
+    const double vox = (double)B * D * D * D;
+    const double bytes = vox * 2.0 * (L.cin + (EPI == EPI_FINAL ? 2 : L.cout));
+    ProfScope ps(c, L.name, 2.0 * L.macs_per_voxel * vox, bytes);
+    dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.tiles_z), (unsigned)L.nsplit);
+    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI>), grid, dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return SN_OK;
+}
+
+static int launch_pool(sn_ctx *c, const char *tag, const _Float16 *in, _Float16 *out, int B, int D, int C)
+{
+    const long long total = (long long)B * (D / 2) * (D / 2) * (D / 2) * (C / 8);
+    ProfScope ps(c, tag, 0, (double)B * D * D * D * C * 2.0 * 1.125);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, in, out, D, C, total);
+    HIPCHK(hipGetLastError());
+    return SN_OK;
+}
+
+template <int F>
+static int launch_up(sn_ctx *c, const char *tag, const _Float16 *in, _Float16 *cat, int B, int Di, int cat_cs, int coff)
+{
+    const int Do = Di * F;
+    const long long total = (long long)B * Do * Do * Do * 2;
+    ProfScope ps(c, tag, 0, (double)B * Do * Do * Do * 16 * 2.0);
+    hipLaunchKernelGGL((upsample_cat_kernel<F>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, in, cat, Di,
+                       cat_cs, coff, total);
+    HIPCHK(hipGetLastError());
+    return SN_OK;
+}
+
+// x0 [S][s^3][8] fp16 -> unf [S][s^3] fp32 surface probabilities (nets/SurfaceNet.py:18-76)
+static int run_net(sn_ctx *c, int S, float *unf)
+{
+    const int s = c->s, D2 = s / 2, D3 = s / 4;
+    int rc;
+#define RUN(x) do { if ((rc = (x)) != SN_OK) return rc; } while (0)
+    auto &L = c->conv;
+    RUN((launch_conv<3, 1, 8, 2, EPI_STORE>(c, L["conv1_1"], c->x0, 8, c->a1, 32, 0, 32, nullptr, S, s)));
+    RUN((launch_conv<3, 1, 8, 2, EPI_STORE>(c, L["conv1_2"], c->a1, 32, c->b1, 32, 0, 32, nullptr, S, s)));
+    RUN((launch_conv<3, 1, 8, 2, EPI_STORE>(c, L["conv1_3"], c->b1, 32, c->a1, 32, 0, 32, nullptr, S, s)));
+    RUN((launch_conv<1, 1, 4, 1, EPI_STORE>(c, L["side_op1"], c->a1, 32, c->cat, 64, 0, 16, nullptr, S, s)));
+    RUN(launch_pool(c, "pool1", c->a1, c->p1, S, s, 32));
+    RUN((launch_conv<3, 1, 4, 5, EPI_STORE>(c, L["conv2_1"], c->p1, 32, c->a2, 80, 0, 80, nullptr, S, D2)));
+    RUN((launch_conv<3, 1, 4, 5, EPI_STORE>(c, L["conv2_2"], c->a2, 80, c->b2, 80, 0, 80, nullptr, S, D2)));
+    RUN((launch_conv<3, 1, 4, 5, EPI_STORE>(c, L["conv2_3"], c->b2, 80, c->a2, 80, 0, 80, nullptr, S, D2)));
+    RUN((launch_conv<1, 1, 4, 1, EPI_STORE>(c, L["side_op2"], c->a2, 80, c->s2, 16, 0, 16, nullptr, S, D2)));
+    RUN(launch_up<2>(c, "side_op2_deconv", c->s2, c->cat, S, D2, 64, 16));
+    RUN(launch_pool(c, "pool2", c->a2, c->p2, S, D2, 80));
+    RUN((launch_conv<3, 1, 4, 10, EPI_STORE>(c, L["conv3_1"], c->p2, 80, c->a3, 160, 0, 160, nullptr, S, D3)));
+    RUN((launch_conv<3, 1, 4, 10, EPI_STORE>(c, L["conv3_2"], c->a3, 160, c->b3, 160, 0, 160, nullptr, S, D3)));
+    RUN((launch_conv<3, 1, 4, 10, EPI_STORE>(c, L["conv3_3"], c->b3, 160, c->a3, 160, 0, 160, nullptr, S, D3)));
+    RUN((launch_conv<1, 1, 4, 1, EPI_STORE>(c, L["side_op3"], c->a3, 160, c->s3, 16, 0, 16, nullptr, S, D3)));
+    RUN(launch_up<4>(c, "side_op3_deconv", c->s3, c->cat, S, D3, 64, 32));
+    RUN((launch_conv<3, 2, 4, 10, EPI_STORE>(c, L["conv4_1"], c->a3, 160, c->a4, 304, 0, 304, nullptr, S, D3)));
+    RUN((launch_conv<3, 2, 4, 10, EPI_STORE>(c, L["conv4_2"], c->a4, 304, c->b4, 304, 0, 304, nullptr, S, D3)));
+    RUN((launch_conv<3, 2, 4, 10, EPI_STORE>(c, L["conv4_3"], c->b4, 304, c->a4, 304, 0, 304, nullptr, S, D3)));
+    RUN((launch_conv<1, 1, 4, 1, EPI_STORE>(c, L["side_op4"], c->a4, 304, c->s4, 16, 0, 16, nullptr, S, D3)));
+    RUN(launch_up<4>(c, "side_op4_deconv", c->s4, c->cat, S, D3, 64, 48));
+    RUN((launch_conv<3, 1, 4, 7, EPI_STORE>(c, L["merge_conv_a"], c->cat, 64, c->ma, 104, 0, 104, nullptr, S, s)));
+    RUN((launch_conv<3, 1, 4, 7, EPI_FINAL>(c, L["merge_conv_b"], c->ma, 104, nullptr, 0, 0, 0, unf, S, s)));
+#undef RUN
+    return SN_OK;
+}
+
+static int launch_fuse(sn_ctx *c, const float *unf, const float *w_dev, float *fused, int n, int n_vp)
+{
+    const int s3 = c->s * c->s * c->s;
+    const long long total = (long long)n * s3;
+    ProfScope ps(c, "fusion", 0, (double)total * 4.0 * (n_vp + 1));
+    hipLaunchKernelGGL(fuse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, unf,
+                       n_vp == 1 ? (const float *)nullptr : w_dev, fused, n_vp, s3, total);
+    HIPCHK(hipGetLastError());
+    return SN_OK;
+}
+
+static int launch_cvc(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, const float *xyz_dev, const float *resol_dev,
+                      const float *mean6, float *out_ncdhw, bool sub_mean, _Float16 *out_x0)
+{
+    if (!c->img_base || !c->cams) return fail(SN_ERR_STATE, "sn_set_images / sn_set_cameras must be called before the CVC warp");
+    if (c->V_img != c->V_cam) return fail(SN_ERR_STATE, "image count (%d) != camera count (%d)", c->V_img, c->V_cam);
+    CvcArgs a;
+    memset(&a, 0, sizeof a);
+    a.pairs = pairs_dev; a.xyz = xyz_dev; a.resol = resol_dev; a.cams = c->cams;
+    a.img_base = c->img_base; a.img_off = c->img_off; a.img_h = c->img_h; a.img_w = c->img_w;
+    a.out_ncdhw = out_ncdhw; a.out_x0 = out_x0;
+    static const float kVggMean[6] = {123.68f, 116.779f, 103.939f, 123.68f, 116.779f, 103.939f};  // params.py:129
+    for (int i = 0; i < 6; ++i) a.mean[i] = mean6 ? mean6[i] : kVggMean[i];
+    a.sub_mean_ncdhw = sub_mean ? 1 : 0;
+    a.n_vp = n_vp; a.s = c->s; a.V = c->V_img;
+    const int s3 = c->s * c->s * c->s;
+    const double samples = (double)n * n_vp;
+    // algorithmic bytes: 2 views x s^3 x 3 B gathered + written planes
+    const double bytes = samples * s3 * (6.0 + (out_ncdhw ? 24.0 : 0.0) + (out_x0 ? 16.0 : 0.0));
+    ProfScope ps(c, "cvc_warp", 0, bytes);
+    hipLaunchKernelGGL(cvc_warp_kernel, dim3((unsigned)((s3 + 255) / 256), (unsigned)(n * n_vp)), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return SN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *sn_last_error(void) { return g_err.c_str(); }
+int sn_version(void) { return SN_ABI_VERSION; }
+
+static int create_impl(sn_ctx *c)
+{
+    HIPCHK(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SN_ERR_STATE, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t S = (size_t)c->max_samples, s = (size_t)c->s;
+    const size_t v1 = s * s * s, v2 = v1 / 8, v3 = v1 / 64;
+    int rc;
+#define AL(p, n) do { if ((rc = dev_alloc(c, &c->p, (n))) != SN_OK) return rc; } while (0)
+    AL(x0, S * v1 * 8); AL(a1, S * v1 * 32); AL(b1, S * v1 * 32); AL(cat, S * v1 * 64);
+    AL(p1, S * v2 * 32); AL(a2, S * v2 * 80); AL(b2, S * v2 * 80); AL(s2, S * v2 * 16);
+    AL(p2, S * v3 * 80); AL(a3, S * v3 * 160); AL(b3, S * v3 * 160); AL(a4, S * v3 * 304); AL(b4, S * v3 * 304);
+    AL(s3, S * v3 * 16); AL(s4, S * v3 * 16);
+    AL(ma, S * v1 * 104);
+    AL(unf_ws, S * v1); AL(d_fused, S * v1);
+    AL(d_pairs, S * 2); AL(d_xyz, S * 3); AL(d_resol, S); AL(d_w, S);
+#undef AL
+    return SN_OK;
+}
+
+sn_ctx *sn_create(int device_id, int cube_D, int max_samples)
+{
+    if (cube_D < 8 || cube_D % 4 != 0 || cube_D > 128) { fail(SN_ERR_ARG, "cube_D must be a multiple of 4 in [8,128], got %d", cube_D); return nullptr; }
+    if (max_samples < 1) { fail(SN_ERR_ARG, "max_samples must be >= 1"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fail(SN_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback"); return nullptr; }
+    if (device_id < 0 || device_id >= ndev) { fail(SN_ERR_ARG, "device_id %d out of range [0,%d)", device_id, ndev); return nullptr; }
+    sn_ctx *c = new sn_ctx();
+    c->device = device_id; c->s = cube_D; c->max_samples = max_samples;
+    if (create_impl(c) != SN_OK) { std::string keep = g_err; sn_destroy(c); g_err = keep; return nullptr; }
+    return c;
+}
+
+void sn_destroy(sn_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (void *p : c->owned) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sn_synchronize(sn_ctx *c)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
+int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params)
+{
+    if (!c || !blob || !descs) return fail(SN_ERR_ARG, "null argument");
+    if (n_params != kNetParams && n_params != kAllParams)
+        return fail(SN_ERR_ARG, "expected %d (network) or %d (network + relative-weight MLP) parameter arrays, got %d", kNetParams, kAllParams, n_params);
+    HIPCHK(hipSetDevice(c->device));
+    auto count = [](const sn_param_desc &d) { size_t n = 1; for (int i = 0; i < d.ndim; ++i) n *= (size_t)d.shape[i]; return n; };
+    for (int i = 0; i < n_params; ++i) {
+        if (descs[i].ndim < 1 || descs[i].ndim > 5) return fail(SN_ERR_ARG, "param %d: ndim %d", i, descs[i].ndim);
+        if (descs[i].offset < 0 || (size_t)descs[i].offset + count(descs[i]) > n_floats)
+            return fail(SN_ERR_ARG, "param %d: [offset, offset+size) outside the blob", i);
+    }
+    // free previously loaded weights
+    for (auto &kv : c->conv) { dev_free_owned(c, kv.second.wpack); dev_free_owned(c, kv.second.scale); dev_free_owned(c, kv.second.shift); }
+    c->conv.clear();
+    c->have_weights = false;
+
+    int pi = 0, rc;
+    for (int li = 0; li < kNumSpecs; ++li) {
+        const LayerSpec &sp = kSpecs[li];
+        if (sp.kind == K_UP) {
+            const int k = sp.cin;
+            if (!shape_is(descs[pi], {1, 1, k, k, k})) return fail(SN_ERR_ARG, "%s: W must be (1,1,%d,%d,%d)", sp.name, k, k, k);
+            // fixed kernel of nets/layers.py:363-374; the closed form in upsample_cat_kernel assumes it
+            const float *W = blob + descs[pi].offset;
+            const int factor = (k + 1) / 2;
+            for (int a = 0; a < k; ++a) for (int b2 = 0; b2 < k; ++b2) for (int d = 0; d < k; ++d) {
+                const float e = (1.f - fabsf((float)(a - (factor - 1))) / factor) * (1.f - fabsf((float)(b2 - (factor - 1))) / factor) *
+                                (1.f - fabsf((float)(d - (factor - 1))) / factor);
+                if (fabsf(W[(a * k + b2) * k + d] - e) > 1e-5f)
+                    return fail(SN_ERR_ARG, "%s: interpolation kernel differs from the fixed __W_5D__ stencil; unsupported", sp.name);
+            }
+            ++pi;
+            continue;
+        }
+        const int k = (sp.kind == K_CONV3 || sp.kind == K_DIL3) ? 3 : 1;
+        const bool transposed = (sp.kind == K_DIL3 || sp.kind == K_DIL1);  // stored (C_in, C_out, ...): nets/layers.py:200-213
+        const sn_param_desc &dW = descs[pi];
+        if (!(transposed ? shape_is(dW, {sp.cin, sp.cout, k, k, k}) : shape_is(dW, {sp.cout, sp.cin, k, k, k})))
+            return fail(SN_ERR_ARG, "%s: unexpected W shape", sp.name);
+        for (int j = 1; j <= 4; ++j)
+            if (!shape_is(descs[pi + j], {sp.cout})) return fail(SN_ERR_ARG, "%s: BN vector %d must have shape (%d,)", sp.name, j, sp.cout);
+        const float *W = blob + dW.offset;
+        const float *beta = blob + descs[pi + 1].offset, *gamma = blob + descs[pi + 2].offset;
+        const float *mean = blob + descs[pi + 3].offset, *inv_std = blob + descs[pi + 4].offset;
+        pi += 5;
+        std::vector<float> Wt;
+        const int ntap = k * k * k;
+        if (transposed) {
+            Wt.resize((size_t)sp.cin * sp.cout * ntap);
+            for (int ci = 0; ci < sp.cin; ++ci)
+                for (int o = 0; o < sp.cout; ++o)
+                    for (int t = 0; t < ntap; ++t) Wt[((size_t)o * sp.cin + ci) * ntap + t] = W[((size_t)ci * sp.cout + o) * ntap + t];
+            W = Wt.data();
+        }
+        if (strcmp(sp.name, "merge_conv3") == 0) {
+            // fused into merge_conv_b's epilogue in fp32
+            std::vector<float> w3(7 * 16 + 16, 0.f);
+            for (int ci = 0; ci < sp.cin; ++ci) w3[ci] = W[ci];
+            if (c->w3) dev_free_owned(c, c->w3);
+            if ((rc = dev_alloc(c, &c->w3, w3.size())) != SN_OK) return rc;
+            HIPCHK(hipMemcpy(c->w3, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
+            c->scale3 = gamma[0] * inv_std[0];
+            c->shift3 = beta[0] - mean[0] * c->scale3;
+            continue;
+        }
+        PackedConv L;
+        L.name = sp.name; L.cin = sp.cin; L.cout = sp.cout; L.ks = k; L.dil = (sp.kind == K_DIL3) ? 2 : 1; L.act = sp.act;
+        const TileChoice tc = tile_for(sp);
+        if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max)) != SN_OK) return rc;
+        c->conv[L.name] = L;
+    }
+    c->have_relw = false;
+    if (n_params == kAllParams) {
+        const sn_param_desc *d = descs + pi;
+        if (!shape_is(d[0], {kDFeature, kHidden}) || !shape_is(d[5], {kHidden, 1}) || !shape_is(d[6], {1}))
+            return fail(SN_ERR_ARG, "relative-weight MLP arrays have unexpected shapes");
+        for (int j = 1; j <= 4; ++j) if (!shape_is(d[j], {kHidden})) return fail(SN_ERR_ARG, "feature_fc1 BN vector shape");
+        std::vector<float> sc(kHidden), sh(kHidden);
+        const float *beta = blob + d[1].offset, *gamma = blob + d[2].offset, *mean = blob + d[3].offset, *inv_std = blob + d[4].offset;
+        for (int j = 0; j < kHidden; ++j) { sc[j] = gamma[j] * inv_std[j]; sh[j] = beta[j] - mean[j] * sc[j]; }
+        if (c->relw_W1) { dev_free_owned(c, c->relw_W1); dev_free_owned(c, c->relw_scale); dev_free_owned(c, c->relw_shift); dev_free_owned(c, c->relw_w2); }
+        if ((rc = dev_alloc(c, &c->relw_W1, (size_t)kDFeature * kHidden)) != SN_OK) return rc;
+        if ((rc = dev_alloc(c, &c->relw_scale, kHidden)) != SN_OK) return rc;
+        if ((rc = dev_alloc(c, &c->relw_shift, kHidden)) != SN_OK) return rc;
+        if ((rc = dev_alloc(c, &c->relw_w2, kHidden)) != SN_OK) return rc;
+        HIPCHK(hipMemcpy(c->relw_W1, blob + d[0].offset, sizeof(float) * kDFeature * kHidden, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->relw_scale, sc.data(), sizeof(float) * kHidden, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->relw_shift, sh.data(), sizeof(float) * kHidden, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->relw_w2, blob + d[5].offset, sizeof(float) * kHidden, hipMemcpyHostToDevice));
+        c->relw_b2 = blob[d[6].offset];
+        c->have_relw = true;
+    }
+    c->have_weights = true;
+    return SN_OK;
+}
+
+int sn_set_images(sn_ctx *c, int V, const uint8_t *const *imgs, const int *H, const int *W)
+{
+    if (!c || V < 1 || !imgs || !H || !W) return fail(SN_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<long long> off(V);
+    long long total = 0;
+    for (int v = 0; v < V; ++v) {
+        if (!imgs[v] || H[v] < 1 || W[v] < 1) return fail(SN_ERR_ARG, "image %d: null or empty", v);
+        off[v] = total;
+        total += (long long)H[v] * W[v] * 3;
+        total = (total + 15) / 16 * 16;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free_owned(c, c->img_base); dev_free_owned(c, c->img_off); dev_free_owned(c, c->img_h); dev_free_owned(c, c->img_w);
+    c->img_base = nullptr; c->img_off = nullptr; c->img_h = c->img_w = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &c->img_base, (size_t)total + 16)) != SN_OK) return rc;
+    if ((rc = dev_alloc(c, &c->img_off, V)) != SN_OK) return rc;
+    if ((rc = dev_alloc(c, &c->img_h, V)) != SN_OK) return rc;
+    if ((rc = dev_alloc(c, &c->img_w, V)) != SN_OK) return rc;
+    for (int v = 0; v < V; ++v) HIPCHK(hipMemcpy(c->img_base + off[v], imgs[v], (size_t)H[v] * W[v] * 3, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->img_off, off.data(), sizeof(long long) * V, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->img_h, H, sizeof(int) * V, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->img_w, W, sizeof(int) * V, hipMemcpyHostToDevice));
+    c->V_img = V;
+    return SN_OK;
+}
+
+int sn_set_cameras(sn_ctx *c, int V, const double *P)
+{
+    if (!c || V < 1 || !P) return fail(SN_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free_owned(c, c->cams);
+    c->cams = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &c->cams, (size_t)V * 12)) != SN_OK) return rc;
+    HIPCHK(hipMemcpy(c->cams, P, sizeof(double) * 12 * V, hipMemcpyHostToDevice));
+    c->V_cam = V;
+    return SN_OK;
+}
+
+// ---- device-resident entry points ------------------------------------------------------------------
+static int check_batch(sn_ctx *c, int n, int n_vp, bool need_w)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    if (n < 1 || n_vp < 1) return fail(SN_ERR_ARG, "n and n_vp must be >= 1 (got %d, %d)", n, n_vp);
+    if ((long long)n * n_vp > c->max_samples)
+        return fail(SN_ERR_ARG, "n*n_vp = %lld exceeds the context's max_samples = %d", (long long)n * n_vp, c->max_samples);
+    if (need_w && !c->have_weights) return fail(SN_ERR_STATE, "sn_load_weights has not been called");
+    return SN_OK;
+}
+
+int sn_cvc_dev(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, const float *xyz_dev, const float *resol_dev,
+               const float *mean6, float *out_dev)
+{
+    int rc = check_batch(c, n, n_vp, false);
+    if (rc != SN_OK) return rc;
+    if (!pairs_dev || !xyz_dev || !resol_dev || !out_dev) return fail(SN_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(c->device));
+    return launch_cvc(c, n, n_vp, pairs_dev, xyz_dev, resol_dev, mean6, out_dev, mean6 != nullptr, nullptr);
+}
+
+int sn_forward_dev(sn_ctx *c, int n, int n_vp, const float *X_dev, const float *w_dev, float *fused_dev, float *unfused_dev)
+{
+    int rc = check_batch(c, n, n_vp, true);
+    if (rc != SN_OK) return rc;
+    if (!X_dev || !fused_dev || (n_vp > 1 && !w_dev)) return fail(SN_ERR_ARG, "null device pointer (w is required when n_vp >= 2)");
+    HIPCHK(hipSetDevice(c->device));
+    const int S = n * n_vp, s3 = c->s * c->s * c->s;
+    {
+        ProfScope ps(c, "ncdhw_to_x0", 0, (double)S * s3 * (24.0 + 16.0));
+        hipLaunchKernelGGL(ncdhw_to_x0_kernel, dim3((unsigned)((s3 + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, X_dev, c->x0, s3, S);
+        HIPCHK(hipGetLastError());
+    }
+    float *unf = unfused_dev ? unfused_dev : c->unf_ws;
+    if ((rc = run_net(c, S, unf)) != SN_OK) return rc;
+    return launch_fuse(c, unf, w_dev, fused_dev, n, n_vp);
+}
+
+int sn_cvc_forward_dev(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, const float *xyz_dev, const float *resol_dev,
+                       const float *mean6, const float *w_dev, float *fused_dev, float *unfused_dev, float *cvc_out_dev)
+{
+    int rc = check_batch(c, n, n_vp, true);
+    if (rc != SN_OK) return rc;
+    if (!pairs_dev || !xyz_dev || !resol_dev || !fused_dev || (n_vp > 1 && !w_dev)) return fail(SN_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = launch_cvc(c, n, n_vp, pairs_dev, xyz_dev, resol_dev, mean6, cvc_out_dev, true, c->x0)) != SN_OK) return rc;
+    float *unf = unfused_dev ? unfused_dev : c->unf_ws;
+    if ((rc = run_net(c, n * n_vp, unf)) != SN_OK) return rc;
+    return launch_fuse(c, unf, w_dev, fused_dev, n, n_vp);
+}
+
+// ---- host-buffer entry points (synchronous, chunked by max_samples) ----------------------------------
+static int validate_pairs(sn_ctx *c, long long count, const int64_t *pairs, std::vector<int64_t> &wrapped)
+{
+    wrapped.assign(pairs, pairs + count);
+    for (long long i = 0; i < count; ++i) {
+        int64_t v = wrapped[i];
+        if (v < -(int64_t)c->V_img || v >= (int64_t)c->V_img)
+            return fail(SN_ERR_ARG, "view index %lld out of range for %d views (the reference raises IndexError here)", (long long)v, c->V_img);
+        if (v < 0) wrapped[i] = v + c->V_img;  // numpy negative indexing
+    }
+    return SN_OK;
+}
+
+static int ensure_dX(sn_ctx *c)
+{
+    if (c->d_X) return SN_OK;
+    return dev_alloc(c, &c->d_X, (size_t)c->max_samples * 6 * c->s * c->s * c->s);
+}
+
+static int upload_batch(sn_ctx *c, int n, int n_vp, const int64_t *pairs, const float *xyz, const float *resol, const float *w)
+{
+    if (pairs) HIPCHK(hipMemcpyAsync(c->d_pairs, pairs, sizeof(int64_t) * 2 * n * n_vp, hipMemcpyHostToDevice, c->stream));
+    if (xyz) HIPCHK(hipMemcpyAsync(c->d_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    if (resol) HIPCHK(hipMemcpyAsync(c->d_resol, resol, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    if (w) HIPCHK(hipMemcpyAsync(c->d_w, w, sizeof(float) * n * n_vp, hipMemcpyHostToDevice, c->stream));
+    return SN_OK;
+}
+
+int sn_cvc(sn_ctx *c, int n, int n_vp, const int64_t *pairs, const float *xyz, const float *resol, const float *mean6, float *out)
+{
+    if (!c || !pairs || !xyz || !resol || !out) return fail(SN_ERR_ARG, "null argument");
+    if (n < 0 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
+    if (n == 0) return SN_OK;
+    if (!c->img_base || !c->cams) return fail(SN_ERR_STATE, "sn_set_images / sn_set_cameras must be called first");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<int64_t> wp;
+    int rc;
+    if ((rc = validate_pairs(c, (long long)n * n_vp * 2, pairs, wp)) != SN_OK) return rc;
+    if ((rc = ensure_dX(c)) != SN_OK) return rc;
+    if (n_vp > c->max_samples) return fail(SN_ERR_ARG, "n_vp exceeds max_samples");
+    const size_t per = (size_t)6 * c->s * c->s * c->s;
+    const int step = c->max_samples / n_vp;
+    for (int i0 = 0; i0 < n; i0 += step) {
+        const int m = std::min(step, n - i0);
+        if ((rc = upload_batch(c, m, n_vp, wp.data() + (size_t)i0 * n_vp * 2, xyz + 3 * (size_t)i0, resol + i0, nullptr)) != SN_OK) return rc;
+        if ((rc = launch_cvc(c, m, n_vp, c->d_pairs, c->d_xyz, c->d_resol, mean6, c->d_X, mean6 != nullptr, nullptr)) != SN_OK) return rc;
+        HIPCHK(hipMemcpyAsync(out + (size_t)i0 * n_vp * per, c->d_X, sizeof(float) * per * m * n_vp, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SN_OK;
+}
+
+int sn_forward(sn_ctx *c, int n, int n_vp, const float *X, const float *w, float *fused, float *unfused)
+{
+    if (!c || !X || !fused) return fail(SN_ERR_ARG, "null argument");
+    if (n < 0 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
+    if (n_vp > 1 && !w) return fail(SN_ERR_ARG, "w is required when n_vp >= 2 (nets/SurfaceNet.py:365-372)");
+    if (n == 0) return SN_OK;
+    if (!c->have_weights) return fail(SN_ERR_STATE, "sn_load_weights has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_dX(c)) != SN_OK) return rc;
+    if (n_vp > c->max_samples) return fail(SN_ERR_ARG, "n_vp exceeds max_samples");
+    const size_t s3 = (size_t)c->s * c->s * c->s, per = 6 * s3;
+    const int step = c->max_samples / n_vp;
+    for (int i0 = 0; i0 < n; i0 += step) {
+        const int m = std::min(step, n - i0);
+        HIPCHK(hipMemcpyAsync(c->d_X, X + (size_t)i0 * n_vp * per, sizeof(float) * per * m * n_vp, hipMemcpyHostToDevice, c->stream));
+        if ((rc = upload_batch(c, m, n_vp, nullptr, nullptr, nullptr, n_vp > 1 ? w + (size_t)i0 * n_vp : nullptr)) != SN_OK) return rc;
+        if ((rc = sn_forward_dev(c, m, n_vp, c->d_X, c->d_w, c->d_fused, c->unf_ws)) != SN_OK) return rc;
+        HIPCHK(hipMemcpyAsync(fused + (size_t)i0 * s3, c->d_fused, sizeof(float) * s3 * m, hipMemcpyDeviceToHost, c->stream));
+        if (unfused) HIPCHK(hipMemcpyAsync(unfused + (size_t)i0 * n_vp * s3, c->unf_ws, sizeof(float) * s3 * m * n_vp, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SN_OK;
+}
+
+int sn_cvc_forward(sn_ctx *c, int n, int n_vp, const int64_t *pairs, const float *xyz, const float *resol, const float *mean6,
+                   const float *w, float *fused, float *unfused, float *cvc_out)
+{
+    if (!c || !pairs || !xyz || !resol || !fused) return fail(SN_ERR_ARG, "null argument");
+    if (n < 0 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
+    if (n_vp > 1 && !w) return fail(SN_ERR_ARG, "w is required when n_vp >= 2");
+    if (n == 0) return SN_OK;
+    if (!c->have_weights) return fail(SN_ERR_STATE, "sn_load_weights has not been called");
+    if (!c->img_base || !c->cams) return fail(SN_ERR_STATE, "sn_set_images / sn_set_cameras must be called first");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<int64_t> wp;
+    int rc;
+    if ((rc = validate_pairs(c, (long long)n * n_vp * 2, pairs, wp)) != SN_OK) return rc;
+    if (cvc_out && (rc = ensure_dX(c)) != SN_OK) return rc;
+    if (n_vp > c->max_samples) return fail(SN_ERR_ARG, "n_vp exceeds max_samples");
+    const size_t s3 = (size_t)c->s * c->s * c->s, per = 6 * s3;
+    const int step = c->max_samples / n_vp;
+    for (int i0 = 0; i0 < n; i0 += step) {
+        const int m = std::min(step, n - i0);
+        if ((rc = upload_batch(c, m, n_vp, wp.data() + (size_t)i0 * n_vp * 2, xyz + 3 * (size_t)i0, resol + i0,
+                               n_vp > 1 ? w + (size_t)i0 * n_vp : nullptr)) != SN_OK) return rc;
+        if ((rc = sn_cvc_forward_dev(c, m, n_vp, c->d_pairs, c->d_xyz, c->d_resol, mean6, c->d_w, c->d_fused, c->unf_ws,
+                                     cvc_out ? c->d_X : nullptr)) != SN_OK) return rc;
+        HIPCHK(hipMemcpyAsync(fused + (size_t)i0 * s3, c->d_fused, sizeof(float) * s3 * m, hipMemcpyDeviceToHost, c->stream));
+        if (unfused) HIPCHK(hipMemcpyAsync(unfused + (size_t)i0 * n_vp * s3, c->unf_ws, sizeof(float) * s3 * m * n_vp, hipMemcpyDeviceToHost, c->stream));
+        if (cvc_out) HIPCHK(hipMemcpyAsync(cvc_out + (size_t)i0 * n_vp * per, c->d_X, sizeof(float) * per * m * n_vp, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SN_OK;
+}
+
+int sn_relative_weights(sn_ctx *c, int n, int n_vp, const float *features, float *weights)
+{
+    if (!c || !features || !weights) return fail(SN_ERR_ARG, "null argument");
+    if (n < 0 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
+    if (n == 0) return SN_OK;
+    if (!c->have_relw) return fail(SN_ERR_STATE, "the relative-weight MLP arrays (params 98..104) were not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t rows = (size_t)n * n_vp;
+    float *d_f = nullptr, *d_z = nullptr, *d_o = nullptr;
+    HIPCHK(hipMalloc((void **)&d_f, rows * kDFeature * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&d_z, rows * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&d_o, rows * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(d_f, features, rows * kDFeature * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(relw_mlp_kernel, dim3((unsigned)rows), dim3(128), 0, c->stream, d_f, c->relw_W1, c->relw_scale, c->relw_shift,
+                       c->relw_w2, c->relw_b2, d_z, kDFeature, kHidden);
+    hipLaunchKernelGGL(relw_softmax_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c->stream, d_z, d_o, n, n_vp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(weights, d_o, rows * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_f); (void)hipFree(d_z); (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(SN_ERR_HIP, "relative-weight MLP failed: %s", hipGetErrorString(e));
+    return SN_OK;
+}
+
+// ---- raw device memory helpers (for hosts without a GPU array library) -------------------------------
+void *sn_dev_alloc(sn_ctx *c, size_t bytes)
+{
+    if (!c) { fail(SN_ERR_ARG, "null context"); return nullptr; }
+    (void)hipSetDevice(c->device);
+    unsigned char *p = nullptr;
+    if (dev_alloc(c, &p, bytes) != SN_OK) return nullptr;
+    return p;
+}
+int sn_dev_free(sn_ctx *c, void *p) { if (!c) return fail(SN_ERR_ARG, "null context"); HIPCHK(hipSetDevice(c->device)); HIPCHK(hipStreamSynchronize(c->stream)); return dev_free_owned(c, p); }
+int sn_memcpy_h2d(sn_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(SN_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+int sn_memcpy_d2h(sn_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(SN_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------------
+int sn_profile_enable(sn_ctx *c, int on)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    int rc = prof_drain(c);
+    c->prof_on = on != 0;
+    return rc;
+}
+int sn_profile_reset(sn_ctx *c)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    int rc = prof_drain(c);
+    for (auto &st : c->prof_stats) { st.ms = 0; st.launches = 0; st.flops = 0; st.bytes = 0; }
+    return rc;
+}
+int sn_profile_count(sn_ctx *c)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    if (prof_drain(c) != SN_OK) return SN_ERR_HIP;
+    return (int)c->prof_stats.size();
+}
+int sn_profile_get(sn_ctx *c, int idx, char *name, int name_cap, double *ms_total, int64_t *launches, double *flops, double *bytes)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    int rc = prof_drain(c);
+    if (rc != SN_OK) return rc;
+    if (idx < 0 || idx >= (int)c->prof_stats.size()) return fail(SN_ERR_ARG, "profile index out of range");
+    const ProfStat &st = c->prof_stats[idx];
+    if (name && name_cap > 0) { strncpy(name, st.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (ms_total) *ms_total = st.ms;
+    if (launches) *launches = st.launches;
+    if (flops) *flops = st.flops;
+    if (bytes) *bytes = st.bytes;
+    return SN_OK;
+}
+
+}  // extern "C"

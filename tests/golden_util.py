@@ -1,0 +1,44 @@
+"""Shared helpers of the test-suite: golden fixtures (tests/golden, produced by oracle/gen_golden.py from the
+reference's own code) and the synthetic inputs of SURVEY §8(d)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MEAN6 = np.asarray([123.68, 116.779, 103.939, 123.68, 116.779, 103.939]).astype(np.float32)
+
+
+def synth_image(seed, H, W):
+    return np.random.RandomState(int(seed)).randint(0, 256, (int(H), int(W), 3)).astype(np.uint8)
+
+
+def cvc_cases():
+    z = np.load(os.path.join(GOLDEN, "cvc_cases.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    out = {}
+    for n in names:
+        out[n] = {k.split("/")[1]: z[k] for k in z.files if k.startswith(n + "/")}
+    return out
+
+
+def case_images(case):
+    H, W = case["HW"]
+    return [synth_image(sd, H, W) for sd in case["seeds"]]
+
+
+def cameras():
+    return np.load(os.path.join(GOLDEN, "cameras.npz"))
+
+
+def synthetic_scene(n, n_vp=2, s=32, seed=0, hw=(1200, 1600)):
+    """SURVEY §8(d) synthetic workload: 2 random-noise views, DTU cameras 1,2, cube corners inside the view frusta."""
+    cams = cameras()["P_dtu"][:2]
+    imgs = [synth_image(1234 + v, hw[0], hw[1]) for v in range(2)]
+    rs = np.random.RandomState(seed)
+    span = 0.4 * s
+    xyz = (rs.rand(n, 3) * 40 + np.array([-20.0, -20.0, 580.0]) - np.array([0, 0, span / 2])).astype(np.float32)
+    resol = np.full(n, 0.4, dtype=np.float32)
+    pair_opts = np.array([[0, 1], [1, 0], [0, 0], [1, 1]], dtype=np.int64)
+    pairs = np.stack([pair_opts[(np.arange(n_vp) + i) % 4] for i in range(n)]).astype(np.int64)
+    w = (np.random.RandomState(seed + 1).rand(n, n_vp) + 0.1).astype(np.float32)
+    return dict(cams=cams, imgs=imgs, xyz=xyz, resol=resol, pairs=pairs, w=w)
