@@ -55,6 +55,17 @@ const char *sn_last_error(void);
 int sn_version(void);
 int sn_synchronize(sn_ctx *ctx);
 
+/* Arithmetic of the 3D-CNN (the CVC warp is always the reference's fp64/int arithmetic):
+ *   SN_PRECISION_F16X3 (default): operands carried as hi+lo pairs of fp16 (22 significant bits), three
+ *       MFMAs per product term, fp32 accumulate -> fp32-class results (L_inf vs fp64 oracle ~1e-5);
+ *   SN_PRECISION_F16: operands rounded to fp16, fp32 accumulate -> 3x faster, L_inf ~2e-3 on BN-normalised
+ *       nets, i.e. above the 1e-3 parity bar; opt-in fast mode.
+ * Call before sn_load_weights (weights are packed for the selected mode). */
+#define SN_PRECISION_F16 0
+#define SN_PRECISION_F16X3 1
+int sn_set_precision(sn_ctx *ctx, int mode);
+int sn_get_precision(sn_ctx *ctx);
+
 /* ---- one-time setup -------------------------------------------------------------------------- */
 /* Replaces lasagne.layers.set_all_param_values(...) in SurfaceNet_inference
  * (nets/SurfaceNet.py:385-402). `descs` lists the 105 arrays of the reference pickle in its order

@@ -26,6 +26,7 @@ struct CvcArgs {
     const int *img_h, *img_w;  // (V,)
     float *out_ncdhw;          // (n*n_vp, 6, s,s,s) or nullptr
     _Float16 *out_x0;          // (n*n_vp, s,s,s, 8) fp16 mean-subtracted, or nullptr
+    long long x0_lo_off;       // != 0: also write the lo plane (value - hi) at out_x0 + x0_lo_off (f16x3 mode)
     float mean[6];
     int sub_mean_ncdhw;        // 1: planar output is value - mean (preprocess), 0: raw 0..255
     int n_vp, s, V;
@@ -80,29 +81,39 @@ __global__ void __launch_bounds__(256) cvc_warp_kernel(CvcArgs a)
     }
     if (a.out_x0) {
         typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-        half8 h;
+        half8 h, l;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) h[c] = (_Float16)(rgb[c] - a.mean[c]);
-        h[6] = (_Float16)0.f;
-        h[7] = (_Float16)0.f;
-        *reinterpret_cast<half8 *>(a.out_x0 + ((size_t)sample * s3 + vox) * 8) = h;
+        for (int c = 0; c < 6; ++c) {
+            const float y = rgb[c] - a.mean[c];
+            h[c] = (_Float16)y;
+            l[c] = (_Float16)(y - (float)h[c]);
+        }
+        h[6] = h[7] = l[6] = l[7] = (_Float16)0.f;
+        _Float16 *o = a.out_x0 + ((size_t)sample * s3 + vox) * 8;
+        *reinterpret_cast<half8 *>(o) = h;
+        if (a.x0_lo_off) *reinterpret_cast<half8 *>(o + a.x0_lo_off) = l;
     }
 }
 
 // NCDHW fp32 (the reference's network input, already mean-subtracted) -> channels-last fp16 x0.
-__global__ void __launch_bounds__(256) ncdhw_to_x0_kernel(const float *X, _Float16 *x0, int s3, int nsamples)
+__global__ void __launch_bounds__(256) ncdhw_to_x0_kernel(const float *X, _Float16 *x0, int s3, int nsamples, long long x0_lo_off)
 {
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const int vox = blockIdx.x * 256 + threadIdx.x;
     const int sample = blockIdx.y;
     if (vox >= s3 || sample >= nsamples) return;
     const float *src = X + (size_t)sample * 6 * s3 + vox;
-    half8 h;
+    half8 h, l;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) h[c] = (_Float16)src[(size_t)c * s3];
-    h[6] = (_Float16)0.f;
-    h[7] = (_Float16)0.f;
-    *reinterpret_cast<half8 *>(x0 + ((size_t)sample * s3 + vox) * 8) = h;
+    for (int c = 0; c < 6; ++c) {
+        const float y = src[(size_t)c * s3];
+        h[c] = (_Float16)y;
+        l[c] = (_Float16)(y - (float)h[c]);
+    }
+    h[6] = h[7] = l[6] = l[7] = (_Float16)0.f;
+    _Float16 *o = x0 + ((size_t)sample * s3 + vox) * 8;
+    *reinterpret_cast<half8 *>(o) = h;
+    if (x0_lo_off) *reinterpret_cast<half8 *>(o + x0_lo_off) = l;
 }
 
 }  // namespace sn

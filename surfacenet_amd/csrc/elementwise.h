@@ -14,7 +14,10 @@ namespace sn {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // in [B][D][D][D][C] -> out [B][D/2][D/2][D/2][C]; one thread = one output voxel x 8 channels.
-__global__ void __launch_bounds__(256) maxpool2_kernel(const _Float16 *in, _Float16 *out, int D, int C, long long total)
+// SPLIT: values are hi+lo pairs of fp16 planes (lo plane at +lo_off elements); the max is taken on hi+lo.
+template <int SPLIT>
+__global__ void __launch_bounds__(256) maxpool2_kernel(const _Float16 *in, _Float16 *out, int D, int C, long long total,
+                                                       long long in_lo_off, long long out_lo_off)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -26,14 +29,31 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const _Float16 *in, _Floa
     const int x = (int)(t % Do);
     const long long b = t / Do;
     const _Float16 *p = in + ((((b * D + 2 * x) * D + 2 * y) * D + 2 * z) * (long long)C) + c8 * 8;
-    h8 m = *reinterpret_cast<const h8 *>(p);
+    h8 m = *reinterpret_cast<const h8 *>(p), ml;
+    float mv[8];
+    if constexpr (SPLIT) {
+        ml = *reinterpret_cast<const h8 *>(p + in_lo_off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mv[e] = (float)m[e] + (float)ml[e];
+    }
 #pragma unroll
     for (int o = 1; o < 8; ++o) {
-        const h8 q = *reinterpret_cast<const h8 *>(p + ((long long)((o >> 2) * D + ((o >> 1) & 1)) * D + (o & 1)) * C);
+        const _Float16 *pq = p + ((long long)((o >> 2) * D + ((o >> 1) & 1)) * D + (o & 1)) * C;
+        const h8 q = *reinterpret_cast<const h8 *>(pq);
+        if constexpr (SPLIT) {
+            const h8 ql = *reinterpret_cast<const h8 *>(pq + in_lo_off);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = q[e] > m[e] ? q[e] : m[e];
+            for (int e = 0; e < 8; ++e) {
+                const float qv = (float)q[e] + (float)ql[e];
+                if (qv > mv[e]) { mv[e] = qv; m[e] = q[e]; ml[e] = ql[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = q[e] > m[e] ? q[e] : m[e];
+        }
     }
     *reinterpret_cast<h8 *>(out + idx * 8) = m;
+    if constexpr (SPLIT) *reinterpret_cast<h8 *>(out + out_lo_off + idx * 8) = ml;
 }
 
 // Per-axis operator of the "bilinear" upsampler: output index o = F*m + ph reads
@@ -55,10 +75,10 @@ __device__ __forceinline__ void up_axis(int o, int n_in, int &m, float &wa, floa
 }
 
 // in [B][Di][Di][Di][16] -> cat [B][Do][Do][Do][cat_cs] channels [coff, coff+16), Do = F*Di.
-// One thread = one output voxel x 8 channels.
-template <int F>
+// One thread = one output voxel x 8 channels. SPLIT: hi/lo fp16 planes in and out.
+template <int F, int SPLIT>
 __global__ void __launch_bounds__(256) upsample_cat_kernel(const _Float16 *in, _Float16 *cat, int Di, int cat_cs, int coff,
-                                                           long long total)
+                                                           long long total, long long in_lo_off, long long out_lo_off)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -82,15 +102,27 @@ __global__ void __launch_bounds__(256) upsample_cat_kernel(const _Float16 *in, _
         const int dx = o >> 2, dy = (o >> 1) & 1, dz = o & 1;
         const float w = (dx ? bx : ax) * (dy ? by : ay) * (dz ? bz : az);
         if (w != 0.f) {
-            const h8 q = *reinterpret_cast<const h8 *>(in + ((((b * Di + mx + dx) * Di + my + dy) * Di + mz + dz) * 16LL) + c8 * 8);
+            const _Float16 *pq = in + ((((b * Di + mx + dx) * Di + my + dy) * Di + mz + dz) * 16LL) + c8 * 8;
+            const h8 q = *reinterpret_cast<const h8 *>(pq);
+            if constexpr (SPLIT) {
+                const h8 ql = *reinterpret_cast<const h8 *>(pq + in_lo_off);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += w * (float)q[e];
+                for (int e = 0; e < 8; ++e) acc[e] += w * ((float)q[e] + (float)ql[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * (float)q[e];
+            }
         }
     }
-    h8 r;
+    h8 r, rl;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (_Float16)acc[e];
-    *reinterpret_cast<h8 *>(cat + ((((b * Do + x) * Do + y) * Do + z) * (long long)cat_cs) + coff + c8 * 8) = r;
+    for (int e = 0; e < 8; ++e) {
+        r[e] = (_Float16)acc[e];
+        if constexpr (SPLIT) rl[e] = (_Float16)(acc[e] - (float)r[e]);
+    }
+    _Float16 *o = cat + ((((b * Do + x) * Do + y) * Do + z) * (long long)cat_cs) + coff + c8 * 8;
+    *reinterpret_cast<h8 *>(o) = r;
+    if constexpr (SPLIT) *reinterpret_cast<h8 *>(o + out_lo_off) = rl;
 }
 
 // unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.

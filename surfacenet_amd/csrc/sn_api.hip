@@ -68,7 +68,7 @@ struct PackedConv {
     int cin = 0, cout = 0, ks = 1, dil = 1, act = 0;
     int cin_p = 0;             // input channels padded to 8
     int nf = 0, nsplit = 1;    // 16-channel fragments per workgroup, workgroup columns
-    int cs8max = 4;
+    int cs8max = 4, split = 0;
     std::vector<unsigned char> slab_c8;
     long long wsplit_stride = 0;   // halfs
     _Float16 *wpack = nullptr;     // device
@@ -88,6 +88,8 @@ struct sn_ctx {
     double *cams = nullptr;
     // weights
     bool have_weights = false, have_relw = false;
+    int split = 1;              // 0: f16 operands; 1: f16x3 (hi/lo split operands, fp32-class results) — default
+    bool ws_ready = false; int ws_split = -1;
     std::map<std::string, PackedConv> conv;
     float *w3 = nullptr; float scale3 = 0, shift3 = 0;
     float *relw_W1 = nullptr, *relw_scale = nullptr, *relw_shift = nullptr, *relw_w2 = nullptr; float relw_b2 = 0;
@@ -95,6 +97,7 @@ struct sn_ctx {
     _Float16 *x0 = nullptr, *a1 = nullptr, *b1 = nullptr, *cat = nullptr, *p1 = nullptr, *a2 = nullptr, *b2 = nullptr,
              *p2 = nullptr, *a3 = nullptr, *b3 = nullptr, *a4 = nullptr, *b4 = nullptr, *s2 = nullptr, *s3 = nullptr,
              *s4 = nullptr, *ma = nullptr;
+    std::vector<void *> ws_owned;
     float *unf_ws = nullptr;      // [max_samples][s^3]
     // batch parameter staging
     int64_t *d_pairs = nullptr; float *d_xyz = nullptr, *d_resol = nullptr, *d_w = nullptr;
@@ -185,19 +188,21 @@ static int prof_drain(sn_ctx *c)
 // weight preparation
 // ------------------------------------------------------------------------------------------------
 // W is given as (cout, cin, k,k,k) row-major fp32 (dilated layers are transposed by the caller).
+// Packed layout: [nsplit][slab][chunk][nf]{ hi fragment (64 lanes x 8 halfs) [, lo fragment] }.
 static int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const float *gamma, const float *mean,
-                     const float *inv_std, int nf, int nsplit, int cs8max)
+                     const float *inv_std, int nf, int nsplit, int cs8max, int split)
 {
-    L.nf = nf; L.nsplit = nsplit; L.cs8max = cs8max;
+    L.nf = nf; L.nsplit = nsplit; L.cs8max = cs8max; L.split = split;
     L.cin_p = round_up(L.cin, 8);
     const int ntap = L.ks * L.ks * L.ks;
     const int c8_total = L.cin_p / 8;
+    const int npl = split ? 2 : 1;
     L.slab_c8.clear();
     for (int left = c8_total; left > 0; left -= cs8max) L.slab_c8.push_back((unsigned char)std::min(left, cs8max));
     if ((int)L.slab_c8.size() > kMaxSlab) return fail(SN_ERR_ARG, "%s: too many channel slabs", L.name.c_str());
     long long chunks = 0;
     for (unsigned char c8n : L.slab_c8) chunks += (ntap * c8n + 3) / 4;
-    L.wsplit_stride = chunks * nf * 512;
+    L.wsplit_stride = chunks * nf * 512 * npl;
     std::vector<_Float16> h((size_t)L.wsplit_stride * nsplit, (_Float16)0.f);
     for (int ns = 0; ns < nsplit; ++ns) {
         _Float16 *dst = h.data() + (size_t)ns * L.wsplit_stride;
@@ -209,15 +214,19 @@ static int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta
                     for (int lane = 0; lane < 64; ++lane) {
                         const int o = (ns * nf + f) * 16 + (lane & 15);
                         const int g = 4 * ch + (lane >> 4);
-                        _Float16 *d8 = dst + (((size_t)ch * nf + f) * 64 + lane) * 8;
+                        _Float16 *d8 = dst + (((size_t)ch * nf + f) * npl * 64 + lane) * 8;
                         if (g >= G || o >= L.cout) continue;
                         const int tap = g / c8n, c8 = g % c8n;
                         for (int j = 0; j < 8; ++j) {
                             const int ci = (c8_0 + c8) * 8 + j;
-                            if (ci < L.cin) d8[j] = (_Float16)W[((size_t)o * L.cin + ci) * ntap + tap];
+                            if (ci >= L.cin) continue;
+                            const float w = W[((size_t)o * L.cin + ci) * ntap + tap];
+                            const _Float16 hi = (_Float16)w;
+                            d8[j] = hi;
+                            if (split) d8[512 + j] = (_Float16)(w - (float)hi);
                         }
                     }
-            dst += (size_t)nchunk * nf * 512;
+            dst += (size_t)nchunk * nf * 512 * npl;
             c8_0 += c8n;
         }
     }
@@ -247,29 +256,34 @@ static bool shape_is(const sn_param_desc &d, std::initializer_list<int> s)
 }
 
 struct TileChoice { int nf, nsplit, cs8max; };
-static TileChoice tile_for(const LayerSpec &sp)
+// Must agree with the kernel instantiations in run_net_t<SPLIT> (launch_conv verifies it).
+static TileChoice tile_for(const LayerSpec &sp, int split)
 {
     if (sp.kind == K_CONV1 || sp.kind == K_DIL1) return {1, 1, 10};
     if (sp.cout == 32) return {2, 1, 4};
     if (sp.cout == 80) return {5, 1, 4};
     if (sp.cout == 160) return {10, 1, 4};
-    if (sp.cout == 300) return {10, 2, 4};
+    if (sp.cout == 300) return {10, 2, split ? 2 : 4};
     return {7, 1, 4};  // cout 100
 }
 
 // ------------------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------------------
-template <int KS, int DIL, int MF, int NF, int EPI>
-static int launch_conv(sn_ctx *c, const PackedConv &L, const _Float16 *in, int in_cs, _Float16 *out, int out_cs,
-                       int out_coff, int out_cp, float *out_f32, int B, int D)
+// A channels-last fp16 activation tensor: hi plane at p, lo plane (f16x3 mode) at p + lo elements.
+struct Act { _Float16 *p; long long lo; };
+
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH>
+static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act out, int out_cs, int out_coff, int out_cp,
+                       float *out_f32, int B, int D)
 {
-    using C = ConvCfg<KS, DIL, MF, NF, EPI>;
-    if (L.nf != NF || L.ks != KS || L.dil != DIL || L.cs8max != C::CS8MAX)
+    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH>;
+    if (L.nf != NF || L.ks != KS || L.dil != DIL || L.cs8max != C::CS8MAX || L.split != SPLIT)
         return fail(SN_ERR_STATE, "%s: packed for a different kernel configuration", L.name.c_str());
     ConvArgs a;
     memset(&a, 0, sizeof a);
-    a.in = in; a.out = out; a.out_f32 = out_f32; a.wpack = L.wpack; a.scale = L.scale; a.shift = L.shift;
+    a.in = in.p; a.in_lo_off = in.lo; a.out = out.p; a.out_lo_off = out.lo; a.out_f32 = out_f32;
+    a.wpack = L.wpack; a.scale = L.scale; a.shift = L.shift;
     a.w3 = c->w3; a.scale3 = c->scale3; a.shift3 = c->shift3;
     a.wsplit_stride = L.wsplit_stride;
     a.in_cs = in_cs; a.out_cs = out_cs; a.out_coff = out_coff; a.out_cp = out_cp;
@@ -279,68 +293,87 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, const _Float16 *in, int i
     a.nslab = (int)L.slab_c8.size();
     for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
     const double vox = (double)B * D * D * D;
-    const double bytes = vox * 2.0 * (L.cin + (EPI == EPI_FINAL ? 2 : L.cout));
+    const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : L.cout));
     ProfScope ps(c, L.name, 2.0 * L.macs_per_voxel * vox, bytes);
     dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.tiles_z), (unsigned)L.nsplit);
-    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI>), grid, dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH>), grid, dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return SN_OK;
 }
 
-static int launch_pool(sn_ctx *c, const char *tag, const _Float16 *in, _Float16 *out, int B, int D, int C)
+template <int SPLIT>
+static int launch_pool(sn_ctx *c, const char *tag, Act in, Act out, int B, int D, int C)
 {
     const long long total = (long long)B * (D / 2) * (D / 2) * (D / 2) * (C / 8);
-    ProfScope ps(c, tag, 0, (double)B * D * D * D * C * 2.0 * 1.125);
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, in, out, D, C, total);
+    ProfScope ps(c, tag, 0, (double)B * D * D * D * C * 2.0 * 1.125 * (SPLIT ? 2 : 1));
+    hipLaunchKernelGGL((maxpool2_kernel<SPLIT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, in.p, out.p, D, C,
+                       total, in.lo, out.lo);
     HIPCHK(hipGetLastError());
     return SN_OK;
 }
 
-template <int F>
-static int launch_up(sn_ctx *c, const char *tag, const _Float16 *in, _Float16 *cat, int B, int Di, int cat_cs, int coff)
+template <int F, int SPLIT>
+static int launch_up(sn_ctx *c, const char *tag, Act in, Act cat, int B, int Di, int cat_cs, int coff)
 {
     const int Do = Di * F;
     const long long total = (long long)B * Do * Do * Do * 2;
-    ProfScope ps(c, tag, 0, (double)B * Do * Do * Do * 16 * 2.0);
-    hipLaunchKernelGGL((upsample_cat_kernel<F>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, in, cat, Di,
-                       cat_cs, coff, total);
+    ProfScope ps(c, tag, 0, (double)B * Do * Do * Do * 16 * 2.0 * (SPLIT ? 2 : 1));
+    hipLaunchKernelGGL((upsample_cat_kernel<F, SPLIT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, in.p, cat.p,
+                       Di, cat_cs, coff, total, in.lo, cat.lo);
     HIPCHK(hipGetLastError());
     return SN_OK;
 }
 
-// x0 [S][s^3][8] fp16 -> unf [S][s^3] fp32 surface probabilities (nets/SurfaceNet.py:18-76)
-static int run_net(sn_ctx *c, int S, float *unf)
+// x0 [S][s^3][8] fp16 -> unf [S][s^3] fp32 surface probabilities (nets/SurfaceNet.py:18-76).
+// Kernel configurations <KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH> per layer family; LDS budgets in DESIGN.md.
+template <int SP>
+static int run_net_t(sn_ctx *c, int S, float *unf)
 {
     const int s = c->s, D2 = s / 2, D3 = s / 4;
+    const long long M = c->max_samples, v1 = (long long)s * s * s, v2 = v1 / 8, v3 = v1 / 64;
+    auto A = [&](_Float16 *p, long long vox, int ch) { return Act{p, SP ? M * vox * ch : 0}; };
+    const Act x0 = A(c->x0, v1, 8), a1 = A(c->a1, v1, 32), b1 = A(c->b1, v1, 32), cat = A(c->cat, v1, 64), p1 = A(c->p1, v2, 32),
+              a2 = A(c->a2, v2, 80), b2 = A(c->b2, v2, 80), s2 = A(c->s2, v2, 16), p2 = A(c->p2, v3, 80), a3 = A(c->a3, v3, 160),
+              b3 = A(c->b3, v3, 160), a4 = A(c->a4, v3, 304), b4 = A(c->b4, v3, 304), s3 = A(c->s3, v3, 16), s4 = A(c->s4, v3, 16),
+              ma = A(c->ma, v1, 104), none = Act{nullptr, 0};
     int rc;
 #define RUN(x) do { if ((rc = (x)) != SN_OK) return rc; } while (0)
+#define CONV1 3, 1, (SP ? 4 : 8), 2, EPI_STORE, SP, 4, (SP ? 4 : 8)
+#define SIDE  1, 1, 4, 1, EPI_STORE, SP, 10, (SP ? 8 : 16)
+#define CONV2 3, 1, 4, 5, EPI_STORE, SP, 4, (SP ? 2 : 3)
+#define CONV3 3, 1, 4, 10, EPI_STORE, SP, 4, (SP ? 1 : 2)
+#define CONV4 3, 2, 4, 10, EPI_STORE, SP, (SP ? 2 : 4), (SP ? 1 : 2)
+#define MERGA 3, 1, 4, 7, EPI_STORE, SP, 4, 2
+#define MERGB 3, 1, 4, 7, EPI_FINAL, SP, 4, 2
     auto &L = c->conv;
-    RUN((launch_conv<3, 1, 8, 2, EPI_STORE>(c, L["conv1_1"], c->x0, 8, c->a1, 32, 0, 32, nullptr, S, s)));
-    RUN((launch_conv<3, 1, 8, 2, EPI_STORE>(c, L["conv1_2"], c->a1, 32, c->b1, 32, 0, 32, nullptr, S, s)));
-    RUN((launch_conv<3, 1, 8, 2, EPI_STORE>(c, L["conv1_3"], c->b1, 32, c->a1, 32, 0, 32, nullptr, S, s)));
-    RUN((launch_conv<1, 1, 4, 1, EPI_STORE>(c, L["side_op1"], c->a1, 32, c->cat, 64, 0, 16, nullptr, S, s)));
-    RUN(launch_pool(c, "pool1", c->a1, c->p1, S, s, 32));
-    RUN((launch_conv<3, 1, 4, 5, EPI_STORE>(c, L["conv2_1"], c->p1, 32, c->a2, 80, 0, 80, nullptr, S, D2)));
-    RUN((launch_conv<3, 1, 4, 5, EPI_STORE>(c, L["conv2_2"], c->a2, 80, c->b2, 80, 0, 80, nullptr, S, D2)));
-    RUN((launch_conv<3, 1, 4, 5, EPI_STORE>(c, L["conv2_3"], c->b2, 80, c->a2, 80, 0, 80, nullptr, S, D2)));
-    RUN((launch_conv<1, 1, 4, 1, EPI_STORE>(c, L["side_op2"], c->a2, 80, c->s2, 16, 0, 16, nullptr, S, D2)));
-    RUN(launch_up<2>(c, "side_op2_deconv", c->s2, c->cat, S, D2, 64, 16));
-    RUN(launch_pool(c, "pool2", c->a2, c->p2, S, D2, 80));
-    RUN((launch_conv<3, 1, 4, 10, EPI_STORE>(c, L["conv3_1"], c->p2, 80, c->a3, 160, 0, 160, nullptr, S, D3)));
-    RUN((launch_conv<3, 1, 4, 10, EPI_STORE>(c, L["conv3_2"], c->a3, 160, c->b3, 160, 0, 160, nullptr, S, D3)));
-    RUN((launch_conv<3, 1, 4, 10, EPI_STORE>(c, L["conv3_3"], c->b3, 160, c->a3, 160, 0, 160, nullptr, S, D3)));
-    RUN((launch_conv<1, 1, 4, 1, EPI_STORE>(c, L["side_op3"], c->a3, 160, c->s3, 16, 0, 16, nullptr, S, D3)));
-    RUN(launch_up<4>(c, "side_op3_deconv", c->s3, c->cat, S, D3, 64, 32));
-    RUN((launch_conv<3, 2, 4, 10, EPI_STORE>(c, L["conv4_1"], c->a3, 160, c->a4, 304, 0, 304, nullptr, S, D3)));
-    RUN((launch_conv<3, 2, 4, 10, EPI_STORE>(c, L["conv4_2"], c->a4, 304, c->b4, 304, 0, 304, nullptr, S, D3)));
-    RUN((launch_conv<3, 2, 4, 10, EPI_STORE>(c, L["conv4_3"], c->b4, 304, c->a4, 304, 0, 304, nullptr, S, D3)));
-    RUN((launch_conv<1, 1, 4, 1, EPI_STORE>(c, L["side_op4"], c->a4, 304, c->s4, 16, 0, 16, nullptr, S, D3)));
-    RUN(launch_up<4>(c, "side_op4_deconv", c->s4, c->cat, S, D3, 64, 48));
-    RUN((launch_conv<3, 1, 4, 7, EPI_STORE>(c, L["merge_conv_a"], c->cat, 64, c->ma, 104, 0, 104, nullptr, S, s)));
-    RUN((launch_conv<3, 1, 4, 7, EPI_FINAL>(c, L["merge_conv_b"], c->ma, 104, nullptr, 0, 0, 0, unf, S, s)));
+    RUN((launch_conv<CONV1>(c, L["conv1_1"], x0, 8, a1, 32, 0, 32, nullptr, S, s)));
+    RUN((launch_conv<CONV1>(c, L["conv1_2"], a1, 32, b1, 32, 0, 32, nullptr, S, s)));
+    RUN((launch_conv<CONV1>(c, L["conv1_3"], b1, 32, a1, 32, 0, 32, nullptr, S, s)));
+    RUN((launch_conv<SIDE>(c, L["side_op1"], a1, 32, cat, 64, 0, 16, nullptr, S, s)));
+    RUN((launch_pool<SP>(c, "pool1", a1, p1, S, s, 32)));
+    RUN((launch_conv<CONV2>(c, L["conv2_1"], p1, 32, a2, 80, 0, 80, nullptr, S, D2)));
+    RUN((launch_conv<CONV2>(c, L["conv2_2"], a2, 80, b2, 80, 0, 80, nullptr, S, D2)));
+    RUN((launch_conv<CONV2>(c, L["conv2_3"], b2, 80, a2, 80, 0, 80, nullptr, S, D2)));
+    RUN((launch_conv<SIDE>(c, L["side_op2"], a2, 80, s2, 16, 0, 16, nullptr, S, D2)));
+    RUN((launch_up<2, SP>(c, "side_op2_deconv", s2, cat, S, D2, 64, 16)));
+    RUN((launch_pool<SP>(c, "pool2", a2, p2, S, D2, 80)));
+    RUN((launch_conv<CONV3>(c, L["conv3_1"], p2, 80, a3, 160, 0, 160, nullptr, S, D3)));
+    RUN((launch_conv<CONV3>(c, L["conv3_2"], a3, 160, b3, 160, 0, 160, nullptr, S, D3)));
+    RUN((launch_conv<CONV3>(c, L["conv3_3"], b3, 160, a3, 160, 0, 160, nullptr, S, D3)));
+    RUN((launch_conv<SIDE>(c, L["side_op3"], a3, 160, s3, 16, 0, 16, nullptr, S, D3)));
+    RUN((launch_up<4, SP>(c, "side_op3_deconv", s3, cat, S, D3, 64, 32)));
+    RUN((launch_conv<CONV4>(c, L["conv4_1"], a3, 160, a4, 304, 0, 304, nullptr, S, D3)));
+    RUN((launch_conv<CONV4>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
+    RUN((launch_conv<CONV4>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
+    RUN((launch_conv<SIDE>(c, L["side_op4"], a4, 304, s4, 16, 0, 16, nullptr, S, D3)));
+    RUN((launch_up<4, SP>(c, "side_op4_deconv", s4, cat, S, D3, 64, 48)));
+    RUN((launch_conv<MERGA>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
+    RUN((launch_conv<MERGB>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
 #undef RUN
     return SN_OK;
 }
+
+static int run_net(sn_ctx *c, int S, float *unf) { return c->split ? run_net_t<1>(c, S, unf) : run_net_t<0>(c, S, unf); }
 
 static int launch_fuse(sn_ctx *c, const float *unf, const float *w_dev, float *fused, int n, int n_vp)
 {
@@ -363,6 +396,7 @@ static int launch_cvc(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, cons
     a.pairs = pairs_dev; a.xyz = xyz_dev; a.resol = resol_dev; a.cams = c->cams;
     a.img_base = c->img_base; a.img_off = c->img_off; a.img_h = c->img_h; a.img_w = c->img_w;
     a.out_ncdhw = out_ncdhw; a.out_x0 = out_x0;
+    a.x0_lo_off = (out_x0 && c->split) ? (long long)c->max_samples * c->s * c->s * c->s * 8 : 0;
     static const float kVggMean[6] = {123.68f, 116.779f, 103.939f, 123.68f, 116.779f, 103.939f};  // params.py:129
     for (int i = 0; i < 6; ++i) a.mean[i] = mean6 ? mean6[i] : kVggMean[i];
     a.sub_mean_ncdhw = sub_mean ? 1 : 0;
@@ -370,7 +404,7 @@ static int launch_cvc(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, cons
     const int s3 = c->s * c->s * c->s;
     const double samples = (double)n * n_vp;
     // algorithmic bytes: 2 views x s^3 x 3 B gathered + written planes
-    const double bytes = samples * s3 * (6.0 + (out_ncdhw ? 24.0 : 0.0) + (out_x0 ? 16.0 : 0.0));
+    const double bytes = samples * s3 * (6.0 + (out_ncdhw ? 24.0 : 0.0) + (out_x0 ? 16.0 * (c->split ? 2 : 1) : 0.0));
     ProfScope ps(c, "cvc_warp", 0, bytes);
     hipLaunchKernelGGL(cvc_warp_kernel, dim3((unsigned)((s3 + 255) / 256), (unsigned)(n * n_vp)), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
@@ -394,17 +428,33 @@ static int create_impl(sn_ctx *c)
         return fail(SN_ERR_STATE, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t S = (size_t)c->max_samples, s = (size_t)c->s;
-    const size_t v1 = s * s * s, v2 = v1 / 8, v3 = v1 / 64;
+    const size_t v1 = s * s * s;
     int rc;
 #define AL(p, n) do { if ((rc = dev_alloc(c, &c->p, (n))) != SN_OK) return rc; } while (0)
+    AL(unf_ws, S * v1); AL(d_fused, S * v1);
+    AL(d_pairs, S * 2); AL(d_xyz, S * 3); AL(d_resol, S); AL(d_w, S);
+#undef AL
+    return SN_OK;
+}
+
+// Activation workspace (channels-last fp16; two planes per tensor in f16x3 mode). Sized for max_samples.
+static int ensure_workspace(sn_ctx *c)
+{
+    if (c->ws_ready && c->ws_split == c->split) return SN_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (void *p : c->ws_owned) dev_free_owned(c, p);
+    c->ws_owned.clear();
+    const size_t S = (size_t)c->max_samples, s = (size_t)c->s, npl = c->split ? 2 : 1;
+    const size_t v1 = s * s * s, v2 = v1 / 8, v3 = v1 / 64;
+    int rc;
+#define AL(p, n) do { if ((rc = dev_alloc(c, &c->p, (n) * npl)) != SN_OK) return rc; c->ws_owned.push_back(c->p); } while (0)
     AL(x0, S * v1 * 8); AL(a1, S * v1 * 32); AL(b1, S * v1 * 32); AL(cat, S * v1 * 64);
     AL(p1, S * v2 * 32); AL(a2, S * v2 * 80); AL(b2, S * v2 * 80); AL(s2, S * v2 * 16);
     AL(p2, S * v3 * 80); AL(a3, S * v3 * 160); AL(b3, S * v3 * 160); AL(a4, S * v3 * 304); AL(b4, S * v3 * 304);
     AL(s3, S * v3 * 16); AL(s4, S * v3 * 16);
     AL(ma, S * v1 * 104);
-    AL(unf_ws, S * v1); AL(d_fused, S * v1);
-    AL(d_pairs, S * 2); AL(d_xyz, S * 3); AL(d_resol, S); AL(d_w, S);
 #undef AL
+    c->ws_ready = true; c->ws_split = c->split;
     return SN_OK;
 }
 
@@ -433,6 +483,17 @@ void sn_destroy(sn_ctx *c)
     delete c;
 }
 
+int sn_set_precision(sn_ctx *c, int mode)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    if (mode != SN_PRECISION_F16 && mode != SN_PRECISION_F16X3) return fail(SN_ERR_ARG, "unknown precision mode %d", mode);
+    if (c->have_weights && mode != c->split) c->have_weights = false;   // weights must be re-packed for the new mode
+    c->split = mode;
+    return SN_OK;
+}
+
+int sn_get_precision(sn_ctx *c) { return c ? c->split : SN_ERR_ARG; }
+
 int sn_synchronize(sn_ctx *c)
 {
     if (!c) return fail(SN_ERR_ARG, "null context");
@@ -452,6 +513,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
         if (descs[i].offset < 0 || (size_t)descs[i].offset + count(descs[i]) > n_floats)
             return fail(SN_ERR_ARG, "param %d: [offset, offset+size) outside the blob", i);
     }
+    { int rcw = ensure_workspace(c); if (rcw != SN_OK) return rcw; }
     // free previously loaded weights
     for (auto &kv : c->conv) { dev_free_owned(c, kv.second.wpack); dev_free_owned(c, kv.second.scale); dev_free_owned(c, kv.second.shift); }
     c->conv.clear();
@@ -508,8 +570,8 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
         }
         PackedConv L;
         L.name = sp.name; L.cin = sp.cin; L.cout = sp.cout; L.ks = k; L.dil = (sp.kind == K_DIL3) ? 2 : 1; L.act = sp.act;
-        const TileChoice tc = tile_for(sp);
-        if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max)) != SN_OK) return rc;
+        const TileChoice tc = tile_for(sp, c->split);
+        if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, c->split)) != SN_OK) return rc;
         c->conv[L.name] = L;
     }
     c->have_relw = false;
@@ -609,7 +671,8 @@ int sn_forward_dev(sn_ctx *c, int n, int n_vp, const float *X_dev, const float *
     const int S = n * n_vp, s3 = c->s * c->s * c->s;
     {
         ProfScope ps(c, "ncdhw_to_x0", 0, (double)S * s3 * (24.0 + 16.0));
-        hipLaunchKernelGGL(ncdhw_to_x0_kernel, dim3((unsigned)((s3 + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, X_dev, c->x0, s3, S);
+        hipLaunchKernelGGL(ncdhw_to_x0_kernel, dim3((unsigned)((s3 + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, X_dev, c->x0, s3, S,
+                           c->split ? (long long)c->max_samples * s3 * 8 : 0LL);
         HIPCHK(hipGetLastError());
     }
     float *unf = unfused_dev ? unfused_dev : c->unf_ws;

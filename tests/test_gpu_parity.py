@@ -50,43 +50,55 @@ def test_cvc_bad_view_index(sn):
         assert np.array_equal(a, ctx.cvc(pos, c["xyz"], c["resol"]))
 
 
+# Tolerances (surface probabilities, L_inf):
+#   f16x3 (default, parity grade) vs the fp64 oracle: north-star bar 1e-3; observed ~1e-5, asserted < 1e-4
+#   f16 (fast mode): vs fp64 < 1e-2 (observed 1e-3..4e-3: does NOT meet the 1e-3 bar, hence opt-in); vs the oracle that
+#   emulates fp16 operand storage < 5e-3 (same noise class as the storage rounding itself, because a different
+#   summation order flips half-ulp fp16 roundings of stored activations)
+TOL_X3, TOL_F16_EMU, TOL_F16 = 1e-4, 5e-3, 1e-2
+
+
 def _net_case(s, n, n_vp, seed):
-    from surfacenet_amd import weights
-    values = weights.synthetic_param_values(seed)
-    rs = np.random.RandomState(seed + 10)
-    X = rs.randint(0, 256, (n * n_vp, 6, s, s, s)).astype(np.float32) - golden_util.MEAN6[None, :, None, None, None]
-    w = (rs.rand(n, n_vp) + 0.1).astype(np.float32)
+    import synth
+    values = list(synth.calibrated_params(seed % 3))
+    X = synth.random_cvc(n * n_vp, s, seed + 10)
+    w = (np.random.RandomState(seed).rand(n, n_vp) + 0.1).astype(np.float32)
     return values, X, w
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
 @pytest.mark.parametrize("s,n,n_vp", [(8, 3, 1), (16, 2, 2), (32, 1, 3)])
-def test_forward_vs_oracle(sn, s, n, n_vp):
+def test_forward_vs_oracle(sn, s, n, n_vp, precision):
     from oracle import net_oracle
     values, X, w = _net_case(s, n, n_vp, seed=s)
-    with sn.Context(cube_D=s, max_samples=4) as ctx:       # forces chunking for n*n_vp > 4
+    with sn.Context(cube_D=s, max_samples=4, precision=precision) as ctx:       # forces chunking for n*n_vp > 4
         ctx.load_param_values(values)
         fused, unfused = ctx.forward(X, w if n_vp > 1 else None, n_vp=n_vp)
     assert fused.shape == (n, 1, s, s, s) and unfused.shape == (n, n_vp, s, s, s)
     f64, u64 = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp)
-    f16, u16 = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp, quant="fp16")
-    e_emu = np.abs(unfused - u16).max()
-    e_ref = np.abs(unfused - u64).max()
-    print("s=%d Linf vs fp16-emulating oracle %.3e, vs fp64 oracle %.3e, fused %.3e" % (s, e_emu, e_ref, np.abs(fused - f64).max()))
-    assert e_emu < 3e-4          # same arithmetic, different summation order / rare rounding flips
-    assert e_ref < 5e-3
-    assert np.abs(fused - f16).max() < 3e-4
+    assert u64.std() > 0.05 and u64.min() < 0.2 and u64.max() > 0.8          # the test net is not degenerate
+    e_ref, e_fused = np.abs(unfused - u64).max(), np.abs(fused - f64).max()
+    print("%s s=%d: L_inf vs fp64 oracle: unfused %.3e fused %.3e" % (precision, s, e_ref, e_fused))
+    if precision == "f16x3":
+        assert e_ref < TOL_X3 and e_fused < TOL_X3
+    else:
+        f16, u16 = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp, quant="fp16")
+        e_emu = np.abs(unfused - u16).max()
+        print("   vs fp16-emulating oracle %.3e (emulation itself vs fp64: %.3e)" % (e_emu, np.abs(u16 - u64).max()))
+        assert e_emu < TOL_F16_EMU and e_ref < TOL_F16
     if n_vp == 1:
         assert np.array_equal(fused, unfused)
 
 
-def test_cvc_forward_fused_path(sn):
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_cvc_forward_fused_path(sn, precision):
     from oracle import cvc_oracle, net_oracle
-    from surfacenet_amd import weights
+    import synth
     s, n, n_vp = 16, 3, 2
     sc = golden_util.synthetic_scene(n, n_vp, s=s, seed=5, hw=(600, 800))
     sc["xyz"][1] = [-150.0, -102.0, 638.0]
-    values = weights.synthetic_param_values(1)
-    with sn.Context(cube_D=s, max_samples=4) as ctx:
+    values = list(synth.calibrated_params(1))
+    with sn.Context(cube_D=s, max_samples=4, precision=precision) as ctx:
         ctx.load_param_values(values)
         ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
         fused, unfused, cvc = ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"], sc["w"], return_cvc=True)
@@ -94,5 +106,6 @@ def test_cvc_forward_fused_path(sn):
     ref_cvc = cvc_oracle.gen_coloredCubes(sc["pairs"], sc["xyz"], sc["resol"], sc["cams"], sc["imgs"], s, mean6=golden_util.MEAN6)
     assert np.array_equal(cvc, ref_cvc)
     assert np.array_equal(fused, f2) and np.array_equal(unfused, u2)      # fused entry == 3-call protocol
-    f16, u16 = net_oracle.forward_torch(ref_cvc, values, w=sc["w"], n_vp=n_vp, quant="fp16")
-    assert np.abs(unfused - u16).max() < 3e-4 and np.abs(fused - f16).max() < 3e-4
+    f64, u64 = net_oracle.forward_torch(ref_cvc, values, w=sc["w"], n_vp=n_vp)
+    tol = TOL_X3 if precision == "f16x3" else TOL_F16
+    assert np.abs(unfused - u64).max() < tol and np.abs(fused - f64).max() < tol
