@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsurfacenet_hip.so")
+LIB_PATH = os.environ.get("SURFACENET_HIP_LIB") or os.path.join(_HERE, "libsurfacenet_hip.so")   # override: profiling builds
 
 # Every symbol include/surfacenet_hip.h declares (tests/test_abi.py checks the two lists agree).
 ABI_SYMBOLS = [

@@ -31,6 +31,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+
+// Compile-time ablation switches for profiling experiments (results are WRONG when != 0): 1 stage only the first
+// slab, 2 no per-piece barrier, 4 no MFMAs, 16 no weight-fragment reads, 32 no activation-fragment reads.
+#ifndef SN_ABL
+#define SN_ABL 0
+#endif
 
 namespace sn {
 
@@ -69,11 +76,45 @@ __device__ __forceinline__ void sn_split(float y, _Float16 &hi, _Float16 &lo)
     lo = (_Float16)(y - (float)hi);
 }
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_>
+// ---- inline-asm LDS reads with counted waits (the K loop is software-pipelined by hand: hipcc sinks ds_reads to
+// their first use and waits lgkmcnt(0), which exposes the LDS latency in front of every MFMA group) ----------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128(half8 &d, unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset is 16-bit");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read32(int &d, unsigned addr)
+{
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N < 15 ? N : 15));
+    __builtin_amdgcn_sched_barrier(0);   // keep the MFMAs that consume the data below the wait (guide rule 18)
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
+}
+
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_ = 4>
 struct ConvCfg {
     static constexpr int R = (KS / 2) * DIL;
     static constexpr int XS = MF / 4;  // x-slices per wave
-    static constexpr int TX = 4 * XS, TY = 8, TZ = 8;
+    static constexpr int NW = NW_;                         // waves per workgroup (4: one per SIMD, 8: two per SIMD)
+    static constexpr int NT = NW * 64;
+    static constexpr int TX = NW * XS, TY = 8, TZ = 8;
     static constexpr int HX = TX + 2 * R, HY = TY + 2 * R, HZ = TZ + 2 * R;
     static constexpr int HVOX = HX * HY * HZ;
     static constexpr int CS8MAX = CS8;                     // 8-channel groups per slab
@@ -83,17 +124,20 @@ struct ConvCfg {
     static constexpr int FRAG = 1024 * NPL;                // bytes of one packed weight fragment (hi [+ lo])
     static constexpr int WBUF = PCH * NF * FRAG;
     static constexpr int NTAP = KS * KS * KS;
-    static constexpr int KOFF_N = NTAP * CS8MAX + 4;
+    static constexpr int KOFF_N = NTAP * CS8MAX + 12;      // + 2 chunks of look-ahead padding
     static constexpr int XPLANE = HVOX * VS;
     static constexpr int XT_BYTES = XPLANE * NPL;
     static constexpr int LDS_BYTES = XT_BYTES + 2 * WBUF + KOFF_N * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+    // two workgroups per CU when the LDS allows it: ask the register allocator for <= 256 registers per lane
+    static constexpr int MIN_WAVES_PER_SIMD = (NW == 8 || LDS_BYTES <= 80 * 1024) ? 2 : 1;
 };
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_>
-__global__ void __launch_bounds__(256) conv3d_f16_mfma(ConvArgs a)
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_>
+__global__ void __launch_bounds__(NW_ * 64, (ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_>::MIN_WAVES_PER_SIMD))
+conv3d_f16_mfma(ConvArgs a)
 {
-    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_>;
+    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_>;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     char *xt = lds;
     char *wb = lds + C::XT_BYTES;
@@ -123,6 +167,11 @@ __global__ void __launch_bounds__(256) conv3d_f16_mfma(ConvArgs a)
         xbase[m] = ((hx * C::HY + hy) * C::HZ + hz) * C::VS;
     }
 
+    unsigned xaddr[MF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) xaddr[m] = lds_addr(xt) + (unsigned)xbase[m];
+    const unsigned wb_a = lds_addr(wb) + lane * 16;
+
     const char *wsrc = reinterpret_cast<const char *>(a.wpack + (size_t)blockIdx.y * a.wsplit_stride);
     const _Float16 *in_b = a.in + (size_t)b * D * D * D * a.in_cs;
     int c0 = 0;
@@ -135,7 +184,7 @@ __global__ void __launch_bounds__(256) conv3d_f16_mfma(ConvArgs a)
 
         __syncthreads();  // all reads of the previous slab's tile / table / weight buffers are done
 
-        for (int g = tid; g < nchunk * 4; g += 256) {
+        for (int g = tid; g < (nchunk + 2) * 4; g += C::NT) {
             int o = 0;
             if (g < G) {
                 const int tap = g / c8n, c8 = g - tap * c8n;
@@ -144,24 +193,44 @@ __global__ void __launch_bounds__(256) conv3d_f16_mfma(ConvArgs a)
             }
             koff[g] = o;
         }
-        // halo tile of this channel slab: global -> registers -> LDS, zero outside the volume (= 'same' padding)
-        for (int item = tid; item < C::HVOX * c8n; item += 256) {
-            const int hv = item / c8n, c8 = item - hv * c8n;
-            const int hz = hv % C::HZ, hy = (hv / C::HZ) % C::HY, hx = hv / (C::HZ * C::HY);
-            const int gx = x0 - C::R + hx, gy = y0 - C::R + hy, gz = z0 - C::R + hz;
-            uint4 val = make_uint4(0, 0, 0, 0), val2 = make_uint4(0, 0, 0, 0);
-            if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D) {
-                const _Float16 *p = in_b + ((size_t)(gx * D + gy) * D + gz) * a.in_cs + (c0 + c8) * 8;
-                val = *reinterpret_cast<const uint4 *>(p);
-                if constexpr (SPLIT) val2 = *reinterpret_cast<const uint4 *>(p + a.in_lo_off);
+        // halo tile of this channel slab: global -> registers -> LDS, zero outside the volume (= 'same' padding).
+        // SU items per thread are loaded before any is stored, so SU global round trips overlap instead of serialising.
+        {
+            constexpr int SU = 4;
+            const int total = ((SN_ABL & 1) && slab > 0) ? 0 : C::HVOX * c8n;
+            for (int base = tid; base < total; base += C::NT * SU) {
+                uint4 val[SU], val2[SU];
+                int dsto[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int item = base + u * C::NT;
+                    val[u] = make_uint4(0, 0, 0, 0);
+                    val2[u] = make_uint4(0, 0, 0, 0);
+                    dsto[u] = -1;
+                    if (item < total) {
+                        const int hv = item / c8n, c8 = item - hv * c8n;
+                        const int hz = hv % C::HZ, hy = (hv / C::HZ) % C::HY, hx = hv / (C::HZ * C::HY);
+                        const int gx = x0 - C::R + hx, gy = y0 - C::R + hy, gz = z0 - C::R + hz;
+                        dsto[u] = hv * C::VS + c8 * 16;
+                        if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D) {
+                            const _Float16 *p = in_b + ((size_t)(gx * D + gy) * D + gz) * a.in_cs + (c0 + c8) * 8;
+                            val[u] = *reinterpret_cast<const uint4 *>(p);
+                            if constexpr (SPLIT) val2[u] = *reinterpret_cast<const uint4 *>(p + a.in_lo_off);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u)
+                    if (dsto[u] >= 0) {
+                        *reinterpret_cast<uint4 *>(xt + dsto[u]) = val[u];
+                        if constexpr (SPLIT) *reinterpret_cast<uint4 *>(xt + C::XPLANE + dsto[u]) = val2[u];
+                    }
             }
-            *reinterpret_cast<uint4 *>(xt + hv * C::VS + c8 * 16) = val;
-            if constexpr (SPLIT) *reinterpret_cast<uint4 *>(xt + C::XPLANE + hv * C::VS + c8 * 16) = val2;
         }
         // weight piece 0 -> buffer 0 (LDS-DMA: lane-linear, 1 KiB per wave-instruction)
         {
             const int cnt = (nchunk < C::PCH ? nchunk : C::PCH) * NF * C::NPL;
-            for (int i = wave; i < cnt; i += 4)
+            for (int i = wave; i < cnt; i += C::NW)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(wsrc + (size_t)i * 1024 + lane * 16),
                     (__attribute__((address_space(3))) void *)(wb + i * 1024), 16, 0, 0);
@@ -169,6 +238,35 @@ __global__ void __launch_bounds__(256) conv3d_f16_mfma(ConvArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        // ---- software-pipelined K loop over this slab -------------------------------------------------------------
+        // Register stages: X fragments of chunk c+1 and the tap-offset of chunk c+2 are fetched while chunk c computes
+        // (the halo tile is immutable within a slab, so this runs across the per-piece barrier); the weight fragment
+        // n+1 (or fragment 0 of the next chunk of the same piece) is fetched while fragment n's MFMAs issue.
+        // Every wait below counts only the reads issued AFTER the one being waited for (LDS returns in order).
+        constexpr int NPL = C::NPL;
+        const unsigned koff_a = lds_addr(koff) + kq * 4;
+        half8 xc[NPL][MF], xn[NPL][MF], wr[2][NPL];
+        int ko1, ko2;
+        auto issue_x = [&](half8(&dst)[NPL][MF], int ko) {
+            if constexpr (SN_ABL & 32) return;
+            static_for<0, MF>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const unsigned ad = xaddr[m] + (unsigned)ko;
+                lds_read128<0>(dst[0][m], ad);
+                if constexpr (SPLIT) {
+                    if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(dst[1][m], ad);
+                    else lds_read128<0>(dst[1][m], ad + C::XPLANE);
+                }
+            });
+        };
+        {
+            int k0;
+            lds_read32<0>(k0, koff_a);
+            lds_read32<16>(ko1, koff_a);
+            lgkm_wait<0>();
+            issue_x(xc, k0);
+            lgkm_wait<0>();
+        }
         for (int p = 0; p < npiece; ++p) {
             const int ch0 = p * C::PCH;
             if (p + 1 < npiece) {
@@ -176,43 +274,60 @@ __global__ void __launch_bounds__(256) conv3d_f16_mfma(ConvArgs a)
                 const int cnt = (rem < C::PCH ? rem : C::PCH) * NF * C::NPL;
                 const char *src = wsrc + (size_t)(ch0 + C::PCH) * NF * C::FRAG;
                 char *dst = wb + ((p + 1) & 1) * C::WBUF;
-                for (int i = wave; i < cnt; i += 4)
+                for (int i = wave; i < cnt; i += C::NW)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void *)(src + (size_t)i * 1024 + lane * 16),
                         (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
             }
-            const char *wcur = wb + (p & 1) * C::WBUF;
-#pragma unroll
-            for (int cc = 0; cc < C::PCH; ++cc) {
+            const unsigned wp = wb_a + (p & 1) * C::WBUF;
+            lds_read128<0>(wr[0][0], wp);
+            if constexpr (SPLIT) lds_read128<1024>(wr[0][1], wp);
+            static_for<0, C::PCH>([&](auto ccc) {
+                constexpr int cc = decltype(ccc)::value;
                 const int ch = ch0 + cc;
                 if (ch < nchunk) {
-                    const int ko = koff[ch * 4 + kq];
-                    half8 xh[MF], xl[SPLIT ? MF : 1];
-#pragma unroll
-                    for (int m = 0; m < MF; ++m) {
-                        xh[m] = *reinterpret_cast<const half8 *>(xt + xbase[m] + ko);
-                        if constexpr (SPLIT) xl[m] = *reinterpret_cast<const half8 *>(xt + C::XPLANE + xbase[m] + ko);
-                    }
-#pragma unroll
-                    for (int n = 0; n < NF; ++n) {
-                        const char *wp = wcur + (cc * NF + n) * C::FRAG + lane * 16;
-                        const half8 wh = *reinterpret_cast<const half8 *>(wp);
+                    constexpr int par0 = (cc * NF) & 1;
+                    static_for<0, NF>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        constexpr int cur = (par0 + n) & 1, nxt = cur ^ 1;
+                        constexpr bool more_n = (n + 1 < NF), more_c = (cc + 1 < C::PCH);
+                        constexpr int woff = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::FRAG;
+                        if constexpr ((more_n || more_c) && !(SN_ABL & 16)) {
+                            lds_read128<woff>(wr[nxt][0], wp);
+                            if constexpr (SPLIT) lds_read128<woff + 1024>(wr[nxt][1], wp);
+                        }
+                        lgkm_wait<((more_n || more_c) ? NPL : 0) + (n == 1 ? 1 + MF * NPL : 0)>();
+                        if constexpr (!(SN_ABL & 4)) {
                         if constexpr (SPLIT) {
-                            const half8 wl = *reinterpret_cast<const half8 *>(wp + 1024);
 #pragma unroll
-                            for (int m = 0; m < MF; ++m) {
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[m], acc[m][n], 0, 0, 0);
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[m], acc[m][n], 0, 0, 0);
-                            }
+                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][1], xc[0][m], acc[m][n], 0, 0, 0);
+#pragma unroll
+                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[1][m], acc[m][n], 0, 0, 0);
                         }
 #pragma unroll
-                        for (int m = 0; m < MF; ++m)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][n], 0, 0, 0);
+                        for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[0][m], acc[m][n], 0, 0, 0);
+                        } else {
+                            asm volatile("" :: "v"(wr[cur][0]), "v"(xc[0][0]));
+                        }
+                        if constexpr (n == 0) {
+                            lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
+                            issue_x(xn, ko1);
+                        }
+                    });
+                    lgkm_wait<(cc + 1 < C::PCH) ? NPL : 0>();   // X(c+1) and koff(c+2) have landed; W(c+1,0) may be in flight
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) {
+                        xc[0][m] = xn[0][m];
+                        if constexpr (SPLIT) xc[1][m] = xn[1][m];
                     }
+                    ko1 = ko2;
                 }
+            });
+            lgkm_wait<0>();
+            if constexpr (!(SN_ABL & 2)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
         }
         wsrc += (size_t)nchunk * NF * C::FRAG;
         c0 += c8n;
@@ -247,20 +362,29 @@ __global__ void __launch_bounds__(256) conv3d_f16_mfma(ConvArgs a)
                     if constexpr (SPLIT) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
                 }
             }
-        } else {
-            float part = 0.f;
+        }
+    }
+    if constexpr (EPI == EPI_FINAL) {
+        // fused merge_conv3: ReLU(BN(acc)) . w3 over the NF*16 channels; the per-channel constants are re-read per
+        // voxel fragment (L1/L2 hits) instead of being kept live, which keeps the kernel within 256 registers
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+            float p = 0.f;
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
                 const int nl = n * 16 + kq * 4;
-                const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
-                const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
-                const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.w3 + nl);
+                const f32x4 sc = *reinterpret_cast<const volatile f32x4 *>(a.scale + nl);
+                const f32x4 sh = *reinterpret_cast<const volatile f32x4 *>(a.shift + nl);
+                const f32x4 w3 = *reinterpret_cast<const volatile f32x4 *>(a.w3 + nl);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
+                for (int r = 0; r < 4; ++r) p += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
             }
-            part += __shfl_xor(part, 16);
-            part += __shfl_xor(part, 32);
-            if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(part * a.scale3 + a.shift3);
+            const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
+            const bool valid = gx < D && gy < D && gz < D;
+            const size_t vox = ((size_t)(b * D + gx) * D + gy) * D + gz;
+            p += __shfl_xor(p, 16);
+            p += __shfl_xor(p, 32);
+            if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(p * a.scale3 + a.shift3);
         }
     }
 }

@@ -260,11 +260,11 @@ struct TileChoice { int nf, nsplit, cs8max; };
 static TileChoice tile_for(const LayerSpec &sp, int split)
 {
     if (sp.kind == K_CONV1 || sp.kind == K_DIL1) return {1, 1, 10};
-    if (sp.cout == 32) return {2, 1, 4};
-    if (sp.cout == 80) return {5, 1, 4};
+    if (sp.cout == 32) return {2, 1, split ? 2 : 4};
+    if (sp.cout == 80) return {5, 1, split ? 2 : 4};
     if (sp.cout == 160) return {10, 1, 4};
     if (sp.cout == 300) return {10, 2, split ? 2 : 4};
-    return {7, 1, 4};  // cout 100
+    return {7, 1, split ? 1 : 4};  // cout 100
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -273,11 +273,11 @@ static TileChoice tile_for(const LayerSpec &sp, int split)
 // A channels-last fp16 activation tensor: hi plane at p, lo plane (f16x3 mode) at p + lo elements.
 struct Act { _Float16 *p; long long lo; };
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH>
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH, int NW>
 static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act out, int out_cs, int out_coff, int out_cp,
                        float *out_f32, int B, int D)
 {
-    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH>;
+    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW>;
     if (L.nf != NF || L.ks != KS || L.dil != DIL || L.cs8max != C::CS8MAX || L.split != SPLIT)
         return fail(SN_ERR_STATE, "%s: packed for a different kernel configuration", L.name.c_str());
     ConvArgs a;
@@ -296,7 +296,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : L.cout));
     ProfScope ps(c, L.name, 2.0 * L.macs_per_voxel * vox, bytes);
     dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.tiles_z), (unsigned)L.nsplit);
-    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH>), grid, dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW>), grid, dim3(NW * 64), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return SN_OK;
 }
@@ -338,13 +338,13 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
               ma = A(c->ma, v1, 104), none = Act{nullptr, 0};
     int rc;
 #define RUN(x) do { if ((rc = (x)) != SN_OK) return rc; } while (0)
-#define CONV1 3, 1, (SP ? 4 : 8), 2, EPI_STORE, SP, 4, (SP ? 4 : 8)
-#define SIDE  1, 1, 4, 1, EPI_STORE, SP, 10, (SP ? 8 : 16)
-#define CONV2 3, 1, 4, 5, EPI_STORE, SP, 4, (SP ? 2 : 3)
-#define CONV3 3, 1, 4, 10, EPI_STORE, SP, 4, (SP ? 1 : 2)
-#define CONV4 3, 2, 4, 10, EPI_STORE, SP, (SP ? 2 : 4), (SP ? 1 : 2)
-#define MERGA 3, 1, 4, 7, EPI_STORE, SP, 4, 2
-#define MERGB 3, 1, 4, 7, EPI_FINAL, SP, 4, 2
+#define CONV1 3, 1, (SP ? 4 : 8), 2, EPI_STORE, SP, (SP ? 2 : 4), (SP ? 4 : 8), (SP ? 8 : 4)
+#define SIDE  1, 1, 4, 1, EPI_STORE, SP, 10, (SP ? 8 : 16), 4
+#define CONV2 3, 1, 4, 5, EPI_STORE, SP, (SP ? 2 : 4), (SP ? 2 : 3), (SP ? 8 : 4)
+#define CONV3 3, 1, 4, 10, EPI_STORE, SP, 4, (SP ? 1 : 2), 4
+#define CONV4 3, 2, 4, 10, EPI_STORE, SP, (SP ? 2 : 4), (SP ? 1 : 2), 4
+#define MERGA 3, 1, 4, 7, EPI_STORE, SP, (SP ? 1 : 4), (SP ? 1 : 2), 4
+#define MERGB 3, 1, 4, 7, EPI_FINAL, SP, (SP ? 1 : 4), (SP ? 1 : 2), 4
     auto &L = c->conv;
     RUN((launch_conv<CONV1>(c, L["conv1_1"], x0, 8, a1, 32, 0, 32, nullptr, S, s)));
     RUN((launch_conv<CONV1>(c, L["conv1_2"], a1, 32, b1, 32, 0, 32, nullptr, S, s)));
