@@ -106,21 +106,27 @@ def main():
     s3 = s ** 3
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if use_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     scene = golden_util.synthetic_scene(n, n_vp, s=s, seed=rank)   # each rank owns a different shard of cubes
     values = weights.synthetic_param_values(0)
+    if os.environ.get("BENCH_ZERO_DATA"):   # DVFS experiment only: all-zero operands draw less power
+        values = [np.zeros_like(v) if (v.ndim == 5 and v.shape[2] == 3 and v.shape[0] != 1) else v for v in values]
+        scene["imgs"] = [np.zeros_like(im) for im in scene["imgs"]]
     ctx = surfacenet_amd.Context(cube_D=s, max_samples=n * n_vp, device=local_rank, precision=args.precision)
     ctx.load_param_values(values)
     ctx.set_cameras(scene["cams"])
     ctx.set_images(scene["imgs"])
     d_pairs, d_xyz, d_resol, d_w = (ctx.upload(scene[k]) for k in ("pairs", "xyz", "resol", "w"))
-    if world > 1:
+    if use_dist:
         t_fused = torch.empty(n * s3, dtype=torch.float32, device="cuda")
         t_all = torch.empty(world * n * s3, dtype=torch.float32, device="cuda")
         d_fused = t_fused.data_ptr()
@@ -129,13 +135,13 @@ def main():
 
     def step():
         ctx.cvc_forward_dev(n, n_vp, d_pairs, d_xyz, d_resol, d_w, d_fused)
-        if world > 1:
+        if use_dist:
             ctx.synchronize()
             dist.all_gather_into_tensor(t_all, t_fused)
 
     def barrier_sync():
         ctx.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -153,7 +159,7 @@ def main():
     prof = ctx.profile()
     ctx.profile_enable(False)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -184,6 +190,15 @@ def main():
             out["cvc_warp"] = {"bound": "hbm", "achieved_GBps": round(cvc["bytes"] / (cvc["ms"] * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
                                "avg_launch_ms": round(cvc["ms"] / cvc["launches"], 4)}
         out["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        try:   # HBM-side bytes per launch measured with rocprofv3 PMC passes on this workload (tools/pmc_summary.py)
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt["config"] == {"cube_D": s, "samples": n * n_vp, "precision": args.precision} and dom in pt:
+                out["roofline"]["traffic"] = pt[dom]["read_bytes"] + pt[dom]["write_bytes"]
+                out["roofline"]["traffic_note"] = "bytes/launch, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, Infinity-Cache hits included; L2 hit rate %.2f; profiles/pmc_traffic.json" % pt[dom].get("l2_hit_rate", float("nan"))
+                if cvc and "cvc_warp" in pt:
+                    out["cvc_warp"]["traffic"] = pt["cvc_warp"]["read_bytes"] + pt["cvc_warp"]["write_bytes"]
+        except Exception:
+            pass
         out["roofline"]["note"] = ("achieved = ALGORITHMIC conv FLOPs / kernel time; the f16x3 mode issues 3 MFMA FLOPs per algorithmic "
                                    "FLOP, so its ceiling is frac = 1/3" if args.precision == "f16x3" else "achieved = algorithmic conv FLOPs / kernel time")
         if world == 1 and args.precision == "f16x3" and not args.no_fast_mode:
@@ -191,7 +206,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, values, s, n_vp)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 

@@ -18,25 +18,35 @@
 //                     still 5.3x the f32-input MFMA rate of gfx950 (no xf32/TF32 on this chip).
 //                     Activations live in HBM as two fp16 planes (hi, lo).
 // GEMM view: D[cout][voxel] += W[cout][k] * X[k][voxel], k = (tap, cin) in 8-channel groups.
-//   A operand = weights, pre-packed on the host in fragment order (lane l: cout = l&15,
-//               k = (l>>4)*8 + j) and streamed global -> LDS with global_load_lds_dwordx4;
-//   B operand = activations of a (TX+2R)x(TY+2R)x(TZ+2R) halo tile staged once per channel slab
-//               in LDS and re-read for every one of the 27 taps;
+//   A operand = weights, pre-packed on the host in fragment order (lane l: cout = l&15, k = (l>>4)*8 + j);
+//   B operand = activations of a (TX+2R)x(TY+2R)x(TZ+2R) halo tile, staged per channel slab in LDS and re-read
+//               for every one of the 27 taps through a per-slab tap-offset table;
 //   D         = lane l, reg r: voxel = l&15, cout = (l>>4)*4 + r  -> 4 consecutive channels per lane,
 //               stored as one 8-byte fp16x4 (per plane).
-// Work decomposition: one 256-thread workgroup = 4 waves = TX x 8 x 8 output voxels x (NF*16)
-//   output channels; wave w owns x-slices [w*XS, w*XS+XS); every wave holds all NF channel
-//   fragments, so no activation is re-read for another channel block and the 1x1x1 reduction of
-//   merge_conv3 stays inside a wave.
+// Execution structure (v2):
+//   * PERSISTENT workgroups: grid = (#CUs x workgroups/CU, cout splits); each workgroup walks tiles
+//     blockIdx.x, +gridDim.x, ... so nothing is ever staged behind a cold start except its very first slab.
+//   * Everything that enters LDS arrives by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip): the weight
+//     stream in pieces of PCH K-chunks (double-buffered, continuous across slabs and tiles) and the halo tile
+//     of the NEXT (tile, slab) into the second halo buffer while the current one is being multiplied. Voxels
+//     outside the volume ('same' padding / PadLayer) are fetched from a zero page.
+//   * One barrier per weight piece; the K loop inside a piece is software-pipelined by hand (inline-asm
+//     ds_read_b128 with counted s_waitcnt: hipcc would sink every read to its first use and drain lgkmcnt(0)).
+//   * Workgroup = NW waves = (NW*XS) x 8 x 8 output voxels x (NF*16) output channels; wave w owns x-slices
+//     [w*XS, (w+1)*XS) and all NF channel fragments, so the 1x1x1 reduction of merge_conv3 stays inside a wave.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
 
-// Compile-time ablation switches for profiling experiments (results are WRONG when != 0): 1 stage only the first
-// slab, 2 no per-piece barrier, 4 no MFMAs, 16 no weight-fragment reads, 32 no activation-fragment reads.
+// Compile-time ablation switches for profiling experiments (results are WRONG when != 0): 1 halo staging only for
+// the first slab, 2 no per-piece barrier, 4 no MFMAs, 16 no weight-fragment reads, 32 no activation-fragment reads.
 #ifndef SN_ABL
 #define SN_ABL 0
+#endif
+// cache policy of the halo-tile LDS-DMA (aux bits of global_load_lds; 2 = nt: stream past L2 so the weight stream stays)
+#ifndef SN_HALO_AUX
+#define SN_HALO_AUX 0
 #endif
 
 namespace sn {
@@ -55,11 +65,12 @@ struct ConvArgs {
     const float *scale;   // [nsplit*NF*16]
     const float *shift;
     const float *w3;      // EPI_FINAL: [NF*16] fp32 weights of the fused 1x1x1 conv
+    const void *zero_page;    // >= 16 zero bytes: source of out-of-volume / padding voxels
     float scale3, shift3;
     long long wsplit_stride;  // halfs between channel splits in wpack
     long long in_lo_off, out_lo_off;
     int in_cs, out_cs, out_coff, out_cp;
-    int D, tiles_x, tiles_y, tiles_z;
+    int D, tiles_x, tiles_y, tiles_z, total_tiles;
     int act;              // 0 relu, 1 sigmoid
     int nslab;
     unsigned char slab_c8[kMaxSlab];  // 8-channel groups per slab
@@ -76,8 +87,7 @@ __device__ __forceinline__ void sn_split(float y, _Float16 &hi, _Float16 &lo)
     lo = (_Float16)(y - (float)hi);
 }
 
-// ---- inline-asm LDS reads with counted waits (the K loop is software-pipelined by hand: hipcc sinks ds_reads to
-// their first use and waits lgkmcnt(0), which exposes the LDS latency in front of every MFMA group) ----------------
+// ---- inline-asm LDS reads with counted waits --------------------------------------------------------------------
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f)
 {
@@ -107,83 +117,116 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
 }
+template <int AUX = 0>
+__device__ __forceinline__ void dma16(const void *gsrc, void *lds_dst_wave_base)
+{
+    // 64 lanes x 16 B: lane l's bytes land at lds_dst_wave_base + 16*l (destination is lane-linear by construction)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_dst_wave_base, 16, 0, AUX);
+}
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_ = 4>
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_>
 struct ConvCfg {
     static constexpr int R = (KS / 2) * DIL;
-    static constexpr int XS = MF / 4;  // x-slices per wave
-    static constexpr int NW = NW_;                         // waves per workgroup (4: one per SIMD, 8: two per SIMD)
+    static constexpr int XS = MF / 4;                      // x-slices per wave
+    static constexpr int NW = NW_;                         // waves per workgroup
     static constexpr int NT = NW * 64;
     static constexpr int TX = NW * XS, TY = 8, TZ = 8;
     static constexpr int HX = TX + 2 * R, HY = TY + 2 * R, HZ = TZ + 2 * R;
     static constexpr int HVOX = HX * HY * HZ;
     static constexpr int CS8MAX = CS8;                     // 8-channel groups per slab
-    static constexpr int VS = CS8MAX * 16 + 16;            // LDS bytes per halo voxel (+16: bank spread)
+    static constexpr int SLOTS = CS8 + PADV_;              // 16-byte slots per halo voxel (PADV: one pad slot)
+    static constexpr int VS = SLOTS * 16;                  // LDS bytes per halo voxel
     static constexpr int PCH = PCH_;                       // K-chunks per weight piece (one barrier per piece)
     static constexpr int NPL = SPLIT ? 2 : 1;              // planes (hi, lo)
     static constexpr int FRAG = 1024 * NPL;                // bytes of one packed weight fragment (hi [+ lo])
     static constexpr int WBUF = PCH * NF * FRAG;
     static constexpr int NTAP = KS * KS * KS;
     static constexpr int KOFF_N = NTAP * CS8MAX + 12;      // + 2 chunks of look-ahead padding
-    static constexpr int XPLANE = HVOX * VS;
-    static constexpr int XT_BYTES = XPLANE * NPL;
-    static constexpr int LDS_BYTES = XT_BYTES + 2 * WBUF + KOFF_N * 4;
+    static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
+    static constexpr int XPLANE = NSEG * 1024;
+    static constexpr int XBUF = XPLANE * NPL;
+    static constexpr int LDS_BYTES = 2 * XBUF + 2 * WBUF + 2 * KOFF_N * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
-    // two workgroups per CU when the LDS allows it: ask the register allocator for <= 256 registers per lane
-    static constexpr int MIN_WAVES_PER_SIMD = (NW == 8 || LDS_BYTES <= 80 * 1024) ? 2 : 1;
+    // two 4-wave workgroups per CU only when 256 registers per lane are plausibly enough (accumulators = MF*NF*4)
+    static constexpr int WG_PER_CU = (LDS_BYTES <= 80 * 1024 && NW == 4 && MF * NF <= 32) ? 2 : 1;
+    // two waves per SIMD (8-wave workgroup or two 4-wave workgroups per CU): keep <= 256 registers per lane
+    static constexpr int MIN_WAVES_PER_SIMD = (NW == 8 || WG_PER_CU == 2) ? 2 : 1;
 };
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_>
-__global__ void __launch_bounds__(NW_ * 64, (ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_>::MIN_WAVES_PER_SIMD))
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_>
+__global__ void __launch_bounds__(NW_ * 64, (ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_, PADV_>::MIN_WAVES_PER_SIMD))
 conv3d_f16_mfma(ConvArgs a)
 {
-    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_>;
+    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_, PADV_>;
+    constexpr int NPL = C::NPL;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
-    char *xt = lds;
-    char *wb = lds + C::XT_BYTES;
-    int *koff = reinterpret_cast<int *>(lds + C::XT_BYTES + 2 * C::WBUF);
+    char *const xbuf = lds;                                   // [2][NPL][XPLANE]
+    char *const wbuf = lds + 2 * C::XBUF;                     // [2][WBUF]
+    int *const kbuf = reinterpret_cast<int *>(lds + 2 * C::XBUF + 2 * C::WBUF);   // [2][KOFF_N]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v = lane & 15, kq = lane >> 4;
-
-    int t = blockIdx.x;
-    const int tz = t % a.tiles_z; t /= a.tiles_z;
-    const int ty = t % a.tiles_y; t /= a.tiles_y;
-    const int tx = t % a.tiles_x;
-    const int b = t / a.tiles_x;
-    const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
     const int D = a.D;
+    const int tstride = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile >= a.total_tiles) return;
 
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int m = 0; m < MF; ++m)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char *const wsrc0 = reinterpret_cast<const char *>(a.wpack + (size_t)blockIdx.y * a.wsplit_stride);
 
-    int xbase[MF];
-#pragma unroll
-    for (int m = 0; m < MF; ++m) {
-        const int hx = wave * C::XS + (m >> 2), hy = 2 * (m & 3) + (v >> 3), hz = v & 7;
-        xbase[m] = ((hx * C::HY + hy) * C::HZ + hz) * C::VS;
-    }
-
-    unsigned xaddr[MF];
-#pragma unroll
-    for (int m = 0; m < MF; ++m) xaddr[m] = lds_addr(xt) + (unsigned)xbase[m];
-    const unsigned wb_a = lds_addr(wb) + lane * 16;
-
-    const char *wsrc = reinterpret_cast<const char *>(a.wpack + (size_t)blockIdx.y * a.wsplit_stride);
-    const _Float16 *in_b = a.in + (size_t)b * D * D * D * a.in_cs;
-    int c0 = 0;
-
-    for (int slab = 0; slab < a.nslab; ++slab) {
-        const int c8n = a.slab_c8[slab];
-        const int G = C::NTAP * c8n;
-        const int nchunk = (G + 3) >> 2;
-        const int npiece = (nchunk + C::PCH - 1) / C::PCH;
-
-        __syncthreads();  // all reads of the previous slab's tile / table / weight buffers are done
-
+    // ---- helpers ---------------------------------------------------------------------------------------------
+    auto tile_origin = [&](int t, int &b, int &x0, int &y0, int &z0) {
+        const int tz = t % a.tiles_z; t /= a.tiles_z;
+        const int ty = t % a.tiles_y; t /= a.tiles_y;
+        const int tx = t % a.tiles_x;
+        b = t / a.tiles_x;
+        x0 = tx * C::TX; y0 = ty * C::TY; z0 = tz * C::TZ;
+    };
+    // LDS-DMA of the halo tile of (tile t, channel groups [c0, c0+c8n)) into halo buffer xb. The NSEG*NPL one-KiB
+    // segments are dealt round-robin to the waves; this call issues this wave's instructions [k0, k0+kn) and
+    // returns how many it really issued (the tail waves own one segment less).
+    constexpr int HT = (C::NSEG * NPL + C::NW - 1) / C::NW;   // halo DMA instructions per wave and slab
+    auto stage_halo = [&](int t, int c0, int c8n, int xb, int k0, int kn) -> int {
+        int b, x0, y0, z0;
+        tile_origin(t, b, x0, y0, z0);
+        const _Float16 *in_b = a.in + (size_t)b * D * D * D * a.in_cs;
+        int issued = 0;
+        for (int k = k0; k < k0 + kn; ++k) {
+            const int li = k * C::NW + wave;
+            if (li >= C::NSEG * NPL) break;
+            const int pl = li / C::NSEG, seg = li - pl * C::NSEG;
+            const int slot = seg * 64 + lane;
+            const int hv = slot / C::SLOTS, part = slot - hv * C::SLOTS;
+            const int hz = hv % C::HZ, hy = (hv / C::HZ) % C::HY, hx = hv / (C::HZ * C::HY);
+            const int gx = x0 - C::R + hx, gy = y0 - C::R + hy, gz = z0 - C::R + hz;
+            const bool ok = part < c8n && hv < C::HVOX && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D &&
+                            (unsigned)gz < (unsigned)D;
+            const _Float16 *p = in_b + ((size_t)(gx * D + gy) * D + gz) * a.in_cs + (c0 + part) * 8 + (pl ? a.in_lo_off : 0);
+            dma16<SN_HALO_AUX>(ok ? (const void *)p : a.zero_page, xbuf + xb * C::XBUF + pl * C::XPLANE + seg * 1024);
+            ++issued;
+        }
+        return issued;
+    };
+    // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n; raw s_barrier (a __syncthreads() would make hipcc drain
+    // vmcnt(0) because LDS-DMAs are pending, defeating the counted wait)
+    auto wait_vmcnt = [&](int n) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    auto wg_barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
+    auto write_koff = [&](int c8n, int kb) {
+        const int G = C::NTAP * c8n, nchunk = (G + 3) >> 2;
+        int *k = kbuf + kb * C::KOFF_N;
         for (int g = tid; g < (nchunk + 2) * 4; g += C::NT) {
             int o = 0;
             if (g < G) {
@@ -191,200 +234,227 @@ conv3d_f16_mfma(ConvArgs a)
                 const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
                 o = ((dx * DIL * C::HY + dy * DIL) * C::HZ + dz * DIL) * C::VS + c8 * 16;
             }
-            koff[g] = o;
+            k[g] = o;
         }
-        // halo tile of this channel slab: global -> registers -> LDS, zero outside the volume (= 'same' padding).
-        // SU items per thread are loaded before any is stored, so SU global round trips overlap instead of serialising.
-        {
-            constexpr int SU = 4;
-            const int total = ((SN_ABL & 1) && slab > 0) ? 0 : C::HVOX * c8n;
-            for (int base = tid; base < total; base += C::NT * SU) {
-                uint4 val[SU], val2[SU];
-                int dsto[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int item = base + u * C::NT;
-                    val[u] = make_uint4(0, 0, 0, 0);
-                    val2[u] = make_uint4(0, 0, 0, 0);
-                    dsto[u] = -1;
-                    if (item < total) {
-                        const int hv = item / c8n, c8 = item - hv * c8n;
-                        const int hz = hv % C::HZ, hy = (hv / C::HZ) % C::HY, hx = hv / (C::HZ * C::HY);
-                        const int gx = x0 - C::R + hx, gy = y0 - C::R + hy, gz = z0 - C::R + hz;
-                        dsto[u] = hv * C::VS + c8 * 16;
-                        if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D) {
-                            const _Float16 *p = in_b + ((size_t)(gx * D + gy) * D + gz) * a.in_cs + (c0 + c8) * 8;
-                            val[u] = *reinterpret_cast<const uint4 *>(p);
-                            if constexpr (SPLIT) val2[u] = *reinterpret_cast<const uint4 *>(p + a.in_lo_off);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SU; ++u)
-                    if (dsto[u] >= 0) {
-                        *reinterpret_cast<uint4 *>(xt + dsto[u]) = val[u];
-                        if constexpr (SPLIT) *reinterpret_cast<uint4 *>(xt + C::XPLANE + dsto[u]) = val2[u];
-                    }
-            }
-        }
-        // weight piece 0 -> buffer 0 (LDS-DMA: lane-linear, 1 KiB per wave-instruction)
-        {
-            const int cnt = (nchunk < C::PCH ? nchunk : C::PCH) * NF * C::NPL;
-            for (int i = wave; i < cnt; i += C::NW)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(wsrc + (size_t)i * 1024 + lane * 16),
-                    (__attribute__((address_space(3))) void *)(wb + i * 1024), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    // LDS-DMA of `nch` K-chunks of packed weights starting at byte offset `off` of this split's stream
+    auto stage_w = [&](size_t off, int nch, int wbi) {
+        const int cnt = nch * NF * NPL;
+        const char *src = wsrc0 + ((SN_ABL & 64) ? 0 : off);   // ablation 64: always the same piece (L2-resident)
+        char *dst = wbuf + wbi * C::WBUF;
+        for (int i = wave; i < cnt; i += C::NW) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
+    };
+    auto chunks_of = [&](int c8n) { return (C::NTAP * c8n + 3) >> 2; };
 
-        // ---- software-pipelined K loop over this slab -------------------------------------------------------------
-        // Register stages: X fragments of chunk c+1 and the tap-offset of chunk c+2 are fetched while chunk c computes
-        // (the halo tile is immutable within a slab, so this runs across the per-piece barrier); the weight fragment
-        // n+1 (or fragment 0 of the next chunk of the same piece) is fetched while fragment n's MFMAs issue.
-        // Every wait below counts only the reads issued AFTER the one being waited for (LDS returns in order).
-        constexpr int NPL = C::NPL;
-        const unsigned koff_a = lds_addr(koff) + kq * 4;
-        half8 xc[NPL][MF], xn[NPL][MF], wr[2][NPL];
-        int ko1, ko2;
-        auto issue_x = [&](half8(&dst)[NPL][MF], int ko) {
-            if constexpr (SN_ABL & 32) return;
-            static_for<0, MF>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                const unsigned ad = xaddr[m] + (unsigned)ko;
-                lds_read128<0>(dst[0][m], ad);
-                if constexpr (SPLIT) {
-                    if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(dst[1][m], ad);
-                    else lds_read128<0>(dst[1][m], ad + C::XPLANE);
-                }
-            });
-        };
-        {
-            int k0;
-            lds_read32<0>(k0, koff_a);
-            lds_read32<16>(ko1, koff_a);
-            lgkm_wait<0>();
-            issue_x(xc, k0);
-            lgkm_wait<0>();
-        }
-        for (int p = 0; p < npiece; ++p) {
-            const int ch0 = p * C::PCH;
-            if (p + 1 < npiece) {
-                const int rem = nchunk - (ch0 + C::PCH);
-                const int cnt = (rem < C::PCH ? rem : C::PCH) * NF * C::NPL;
-                const char *src = wsrc + (size_t)(ch0 + C::PCH) * NF * C::FRAG;
-                char *dst = wb + ((p + 1) & 1) * C::WBUF;
-                for (int i = wave; i < cnt; i += C::NW)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(src + (size_t)i * 1024 + lane * 16),
-                        (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
-            }
-            const unsigned wp = wb_a + (p & 1) * C::WBUF;
-            lds_read128<0>(wr[0][0], wp);
-            if constexpr (SPLIT) lds_read128<1024>(wr[0][1], wp);
-            static_for<0, C::PCH>([&](auto ccc) {
-                constexpr int cc = decltype(ccc)::value;
-                const int ch = ch0 + cc;
-                if (ch < nchunk) {
-                    constexpr int par0 = (cc * NF) & 1;
-                    static_for<0, NF>([&](auto nc) {
-                        constexpr int n = decltype(nc)::value;
-                        constexpr int cur = (par0 + n) & 1, nxt = cur ^ 1;
-                        constexpr bool more_n = (n + 1 < NF), more_c = (cc + 1 < C::PCH);
-                        constexpr int woff = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::FRAG;
-                        if constexpr ((more_n || more_c) && !(SN_ABL & 16)) {
-                            lds_read128<woff>(wr[nxt][0], wp);
-                            if constexpr (SPLIT) lds_read128<woff + 1024>(wr[nxt][1], wp);
-                        }
-                        lgkm_wait<((more_n || more_c) ? NPL : 0) + (n == 1 ? 1 + MF * NPL : 0)>();
-                        if constexpr (!(SN_ABL & 4)) {
-                        if constexpr (SPLIT) {
-#pragma unroll
-                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][1], xc[0][m], acc[m][n], 0, 0, 0);
-#pragma unroll
-                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[1][m], acc[m][n], 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[0][m], acc[m][n], 0, 0, 0);
-                        } else {
-                            asm volatile("" :: "v"(wr[cur][0]), "v"(xc[0][0]));
-                        }
-                        if constexpr (n == 0) {
-                            lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
-                            issue_x(xn, ko1);
-                        }
-                    });
-                    lgkm_wait<(cc + 1 < C::PCH) ? NPL : 0>();   // X(c+1) and koff(c+2) have landed; W(c+1,0) may be in flight
-#pragma unroll
-                    for (int m = 0; m < MF; ++m) {
-                        xc[0][m] = xn[0][m];
-                        if constexpr (SPLIT) xc[1][m] = xn[1][m];
-                    }
-                    ko1 = ko2;
-                }
-            });
-            lgkm_wait<0>();
-            if constexpr (!(SN_ABL & 2)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-        }
-        wsrc += (size_t)nchunk * NF * C::FRAG;
-        c0 += c8n;
-    }
-
-    // ---- epilogue: folded BN affine + activation ------------------------------------------------
+    int xbase[MF];
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-        const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
-        const bool valid = gx < D && gy < D && gz < D;
-        const size_t vox = ((size_t)(b * D + gx) * D + gy) * D + gz;
+        const int hx = wave * C::XS + (m >> 2), hy = 2 * (m & 3) + (v >> 3), hz = v & 7;
+        xbase[m] = ((hx * C::HY + hy) * C::HZ + hz) * C::VS;
+    }
+    const unsigned xbuf_a = lds_addr(xbuf), wbuf_a = lds_addr(wbuf) + lane * 16, kbuf_a = lds_addr(kbuf) + kq * 4;
+
+    // ---- prologue: first halo tile, its tap table, first weight piece ----------------------------------------
+    {
+        const int c8n = a.slab_c8[0];
+        stage_halo(tile, 0, c8n, 0, 0, HT);
+        write_koff(c8n, 0);
+        const int nch = chunks_of(c8n);
+        stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        wg_barrier();
+    }
+    int xb = 0;     // halo / tap-table buffer holding the current slab
+    int wbi = 0;    // weight buffer holding the current piece
+
+    for (; tile < a.total_tiles; tile += tstride) {
+        int b, x0, y0, z0;
+        tile_origin(tile, b, x0, y0, z0);
+
+        f32x4 acc[MF][NF];
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        int c0 = 0;
+        size_t woff = 0;   // byte offset of the current slab in the weight stream
+        for (int slab = 0; slab < a.nslab; ++slab) {
+            const int c8n = a.slab_c8[slab];
+            const int nchunk = chunks_of(c8n);
+            const int npiece = (nchunk + C::PCH - 1) / C::PCH;
+            // what comes after this slab: next slab of this tile, or slab 0 of this workgroup's next tile
+            const bool last_slab = slab + 1 == a.nslab;
+            const int ntile = last_slab ? tile + tstride : tile;
+            const bool have_next = ntile < a.total_tiles;
+            const int nslab_i = last_slab ? 0 : slab + 1;
+            const int nc8n = a.slab_c8[nslab_i];
+            const int nc0 = last_slab ? 0 : c0 + c8n;
+            const size_t nwoff = last_slab ? 0 : woff + (size_t)nchunk * NF * C::FRAG;
+            if (have_next) write_koff(nc8n, xb ^ 1);
+            // the next halo tile is fetched in npiece-1 instalments, each issued right after a weight piece so that a
+            // counted vmcnt can wait for the weights while the newest halo DMAs stay in flight
+            const int hq = npiece > 1 ? (HT + npiece - 2) / (npiece - 1) : HT;
+            int hdone = 0;
+
+            // ---- software-pipelined K loop over this slab ----------------------------------------------------
+            // Register stages: X fragments of chunk c+1 and the tap offset of chunk c+2 are fetched while chunk c
+            // computes (the halo buffer is immutable for the whole slab, so this runs across the per-piece barrier);
+            // weight fragment n+1 (or fragment 0 of the next chunk of the piece) is fetched while fragment n's MFMAs
+            // issue. Every wait counts only the reads issued AFTER the one waited for (LDS returns in order).
+            const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
+            unsigned xaddr[MF];
+#pragma unroll
+            for (int m = 0; m < MF; ++m) xaddr[m] = xbuf_a + xb * C::XBUF + (unsigned)xbase[m];
+            half8 xc[NPL][MF], xn[NPL][MF], wr[2][NPL];
+            int ko1, ko2;
+            auto issue_x = [&](half8(&dst)[NPL][MF], int ko) {
+                if constexpr (SN_ABL & 32) return;
+                static_for<0, MF>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    const unsigned ad = xaddr[m] + (unsigned)ko;
+                    lds_read128<0>(dst[0][m], ad);
+                    if constexpr (SPLIT) {
+                        if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(dst[1][m], ad);
+                        else lds_read128<0>(dst[1][m], ad + C::XPLANE);
+                    }
+                });
+            };
+            {
+                int k0;
+                lds_read32<0>(k0, koff_a);
+                lds_read32<16>(ko1, koff_a);
+                lgkm_wait<0>();
+                issue_x(xc, k0);
+                lgkm_wait<0>();
+            }
+            for (int p = 0; p < npiece; ++p) {
+                const int ch0 = p * C::PCH;
+                // first weight fragment of this piece: issue its LDS read before the (VALU-heavy) DMA address work
+                const unsigned wp = wbuf_a + wbi * C::WBUF;
+                lds_read128<0>(wr[0][0], wp);
+                if constexpr (SPLIT) lds_read128<1024>(wr[0][1], wp);
+                // next weight piece: the following piece of this slab, else the first piece of what comes next
+                if (p + 1 < npiece) {
+                    const int rem = nchunk - (ch0 + C::PCH);
+                    stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
+                } else if (have_next) {
+                    const int nch = chunks_of(nc8n);
+                    stage_w(nwoff, nch < C::PCH ? nch : C::PCH, wbi ^ 1);
+                }
+                int hnow = 0;
+                if (have_next && !(SN_ABL & 1) && hdone < HT && (p + 1 < npiece || npiece == 1)) {
+                    hnow = stage_halo(ntile, nc0, nc8n, xb ^ 1, hdone, hq < HT - hdone ? hq : HT - hdone);
+                    hdone += hq;
+                }
+                static_for<0, C::PCH>([&](auto ccc) {
+                    constexpr int cc = decltype(ccc)::value;
+                    const int ch = ch0 + cc;
+                    if (ch < nchunk) {
+                        constexpr int par0 = (cc * NF) & 1;
+                        static_for<0, NF>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            constexpr int cur = (par0 + n) & 1, nxt = cur ^ 1;
+                            constexpr bool more_n = (n + 1 < NF), more_c = (cc + 1 < C::PCH);
+                            constexpr int wo = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::FRAG;
+                            if constexpr ((more_n || more_c) && !(SN_ABL & 16)) {
+                                lds_read128<wo>(wr[nxt][0], wp);
+                                if constexpr (SPLIT) lds_read128<wo + 1024>(wr[nxt][1], wp);
+                            }
+                            lgkm_wait<((more_n || more_c) ? NPL : 0) + (n == 1 ? 1 + MF * NPL : 0)>();
+                            if constexpr (!(SN_ABL & 4)) {
+                                if constexpr (SPLIT) {
+#pragma unroll
+                                    for (int m = 0; m < MF; ++m)
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][1], xc[0][m], acc[m][n], 0, 0, 0);
+#pragma unroll
+                                    for (int m = 0; m < MF; ++m)
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[1][m], acc[m][n], 0, 0, 0);
+                                }
+#pragma unroll
+                                for (int m = 0; m < MF; ++m)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[0][m], acc[m][n], 0, 0, 0);
+                            } else {
+                                asm volatile("" ::"v"(wr[cur][0]), "v"(xc[0][0]));
+                            }
+                            if constexpr (n == 0) {
+                                lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
+                                issue_x(xn, ko1);
+                            }
+                        });
+                        lgkm_wait<(cc + 1 < C::PCH) ? NPL : 0>();   // X(c+1), koff(c+2) landed; W(c+1,0) may be in flight
+#pragma unroll
+                        for (int m = 0; m < MF; ++m) {
+                            xc[0][m] = xn[0][m];
+                            if constexpr (SPLIT) xc[1][m] = xn[1][m];
+                        }
+                        ko1 = ko2;
+                    }
+                });
+                lgkm_wait<0>();
+                if constexpr (!(SN_ABL & 2)) {
+                    wait_vmcnt(p + 1 == npiece ? 0 : hnow);   // next weight piece landed; the newest halo DMAs may still fly
+                    wg_barrier();                             // ... for every wave; this piece's buffers are free again
+                }
+                wbi ^= 1;
+            }
+            xb ^= 1;
+            c0 += c8n;
+            woff += (size_t)nchunk * NF * C::FRAG;
+        }
+
+        // ---- epilogue: folded BN affine + activation --------------------------------------------------------
         if constexpr (EPI == EPI_STORE) {
 #pragma unroll
-            for (int n = 0; n < NF; ++n) {
-                const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
-                if (valid && nl < a.out_cp) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
-                    half4 h, l;
+            for (int m = 0; m < MF; ++m) {
+                const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
+                const bool valid = gx < D && gy < D && gz < D;
+                const size_t vox = ((size_t)(b * D + gx) * D + gy) * D + gz;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float y = acc[m][n][r] * sc[r] + sh[r];
-                        y = a.act == 0 ? fmaxf(y, 0.f) : sn_sigmoid(y);
-                        if constexpr (SPLIT) {
-                            _Float16 hh, ll;
-                            sn_split(y, hh, ll);
-                            h[r] = hh; l[r] = ll;
-                        } else h[r] = (_Float16)y;
+                for (int n = 0; n < NF; ++n) {
+                    const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
+                    if (valid && nl < a.out_cp) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                        half4 h, l;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float y = acc[m][n][r] * sc[r] + sh[r];
+                            y = a.act == 0 ? fmaxf(y, 0.f) : sn_sigmoid(y);
+                            if constexpr (SPLIT) {
+                                _Float16 hh, ll;
+                                sn_split(y, hh, ll);
+                                h[r] = hh; l[r] = ll;
+                            } else h[r] = (_Float16)y;
+                        }
+                        _Float16 *o = a.out + vox * a.out_cs + a.out_coff + nl;
+                        *reinterpret_cast<half4 *>(o) = h;
+                        if constexpr (SPLIT) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
                     }
-                    _Float16 *o = a.out + vox * a.out_cs + a.out_coff + nl;
-                    *reinterpret_cast<half4 *>(o) = h;
-                    if constexpr (SPLIT) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
                 }
             }
-        }
-    }
-    if constexpr (EPI == EPI_FINAL) {
-        // fused merge_conv3: ReLU(BN(acc)) . w3 over the NF*16 channels; the per-channel constants are re-read per
-        // voxel fragment (L1/L2 hits) instead of being kept live, which keeps the kernel within 256 registers
+        } else {
+            // fused merge_conv3: ReLU(BN(acc)) . w3 over the NF*16 channels; the per-channel constants are re-read
+            // per voxel fragment (L1/L2 hits) instead of being kept live, which keeps the kernel within 256 registers
 #pragma unroll
-        for (int m = 0; m < MF; ++m) {
-            float p = 0.f;
+            for (int m = 0; m < MF; ++m) {
+                float p = 0.f;
 #pragma unroll
-            for (int n = 0; n < NF; ++n) {
-                const int nl = n * 16 + kq * 4;
-                const f32x4 sc = *reinterpret_cast<const volatile f32x4 *>(a.scale + nl);
-                const f32x4 sh = *reinterpret_cast<const volatile f32x4 *>(a.shift + nl);
-                const f32x4 w3 = *reinterpret_cast<const volatile f32x4 *>(a.w3 + nl);
+                for (int n = 0; n < NF; ++n) {
+                    const int nl = n * 16 + kq * 4;
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                    const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.w3 + nl);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
+                    for (int r = 0; r < 4; ++r) p += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
+                }
+                const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
+                const bool valid = gx < D && gy < D && gz < D;
+                const size_t vox = ((size_t)(b * D + gx) * D + gy) * D + gz;
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);
+                if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(p * a.scale3 + a.shift3);
             }
-            const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
-            const bool valid = gx < D && gy < D && gz < D;
-            const size_t vox = ((size_t)(b * D + gx) * D + gy) * D + gz;
-            p += __shfl_xor(p, 16);
-            p += __shfl_xor(p, 32);
-            if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(p * a.scale3 + a.shift3);
         }
     }
 }

@@ -125,6 +125,61 @@ __global__ void __launch_bounds__(256) upsample_cat_kernel(const _Float16 *in, _
     if constexpr (SPLIT) *reinterpret_cast<h8 *>(o + out_lo_off) = rl;
 }
 
+// All three upsampled side outputs of one voxel in one pass: cat[...][16..63] = [up2(s2) | up4(s3) | up4(s4)], i.e. the 96
+// contiguous bytes (per plane) that follow side_op1's 16 channels in the ConcatLayer buffer (nets/SurfaceNet.py:71).
+// One thread = one output voxel x one 8-channel group (6 groups per voxel -> 6 consecutive threads write one 96-byte run).
+template <int SPLIT>
+__global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, const _Float16 *s3, const _Float16 *s4, _Float16 *cat,
+                                                            int Do, int cat_cs, long long total, long long lo2, long long lo3,
+                                                            long long lo4, long long out_lo_off)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % 6);
+    long long t = idx / 6;
+    const int z = (int)(t % Do); t /= Do;
+    const int y = (int)(t % Do); t /= Do;
+    const int x = (int)(t % Do);
+    const long long b = t / Do;
+    const int src = g >> 1, c8 = g & 1;                 // 0: s2 (x2), 1: s3 (x4), 2: s4 (x4)
+    const _Float16 *in = src == 0 ? s2 : (src == 1 ? s3 : s4);
+    const long long in_lo = src == 0 ? lo2 : (src == 1 ? lo3 : lo4);
+    const int Di = src == 0 ? Do / 2 : Do / 4;
+    int mx, my, mz;
+    float ax, bx, ay, by, az, bz;
+    if (src == 0) { up_axis<2>(x, Di, mx, ax, bx); up_axis<2>(y, Di, my, ay, by); up_axis<2>(z, Di, mz, az, bz); }
+    else          { up_axis<4>(x, Di, mx, ax, bx); up_axis<4>(y, Di, my, ay, by); up_axis<4>(z, Di, mz, az, bz); }
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int dx = o >> 2, dy = (o >> 1) & 1, dz = o & 1;
+        const float w = (dx ? bx : ax) * (dy ? by : ay) * (dz ? bz : az);
+        if (w != 0.f) {
+            const _Float16 *pq = in + ((((b * Di + mx + dx) * Di + my + dy) * Di + mz + dz) * 16LL) + c8 * 8;
+            const h8 q = *reinterpret_cast<const h8 *>(pq);
+            if constexpr (SPLIT) {
+                const h8 ql = *reinterpret_cast<const h8 *>(pq + in_lo);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * ((float)q[e] + (float)ql[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * (float)q[e];
+            }
+        }
+    }
+    h8 r, rl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r[e] = (_Float16)acc[e];
+        if constexpr (SPLIT) rl[e] = (_Float16)(acc[e] - (float)r[e]);
+    }
+    _Float16 *o = cat + ((((b * Do + x) * Do + y) * Do + z) * (long long)cat_cs) + 16 + g * 8;
+    *reinterpret_cast<h8 *>(o) = r;
+    if constexpr (SPLIT) *reinterpret_cast<h8 *>(o + out_lo_off) = rl;
+}
+
 // unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.
 __global__ void __launch_bounds__(256) fuse_kernel(const float *unfused, const float *w, float *fused, int n_vp, int s3, long long total)
 {

@@ -92,6 +92,7 @@ struct sn_ctx {
     bool ws_ready = false; int ws_split = -1;
     std::map<std::string, PackedConv> conv;
     float *w3 = nullptr; float scale3 = 0, shift3 = 0;
+    void *zero_page = nullptr; int num_cus = 256;
     float *relw_W1 = nullptr, *relw_scale = nullptr, *relw_shift = nullptr, *relw_w2 = nullptr; float relw_b2 = 0;
     // activation workspace (channels-last fp16)
     _Float16 *x0 = nullptr, *a1 = nullptr, *b1 = nullptr, *cat = nullptr, *p1 = nullptr, *a2 = nullptr, *b2 = nullptr,
@@ -259,12 +260,13 @@ struct TileChoice { int nf, nsplit, cs8max; };
 // Must agree with the kernel instantiations in run_net_t<SPLIT> (launch_conv verifies it).
 static TileChoice tile_for(const LayerSpec &sp, int split)
 {
-    if (sp.kind == K_CONV1 || sp.kind == K_DIL1) return {1, 1, 10};
-    if (sp.cout == 32) return {2, 1, split ? 2 : 4};
-    if (sp.cout == 80) return {5, 1, split ? 2 : 4};
-    if (sp.cout == 160) return {10, 1, 4};
-    if (sp.cout == 300) return {10, 2, split ? 2 : 4};
-    return {7, 1, split ? 1 : 4};  // cout 100
+    (void)split;
+    if (sp.kind == K_CONV1 || sp.kind == K_DIL1) return {1, 1, 5};
+    if (sp.kind == K_DIL3) return {5, 4, 1};        // conv4: dilation-2 halo is big -> 8-channel slabs; 4 x 80 output channels
+    if (sp.cout == 32) return {2, 1, 1};
+    if (sp.cout == 80) return {5, 1, 2};
+    if (sp.cout == 160) return {5, 2, 2};
+    return {7, 1, 1};  // cout 100
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -273,30 +275,33 @@ static TileChoice tile_for(const LayerSpec &sp, int split)
 // A channels-last fp16 activation tensor: hi plane at p, lo plane (f16x3 mode) at p + lo elements.
 struct Act { _Float16 *p; long long lo; };
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH, int NW>
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH, int NW, int PADV>
 static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act out, int out_cs, int out_coff, int out_cp,
                        float *out_f32, int B, int D)
 {
-    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW>;
+    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV>;
     if (L.nf != NF || L.ks != KS || L.dil != DIL || L.cs8max != C::CS8MAX || L.split != SPLIT)
         return fail(SN_ERR_STATE, "%s: packed for a different kernel configuration", L.name.c_str());
     ConvArgs a;
     memset(&a, 0, sizeof a);
     a.in = in.p; a.in_lo_off = in.lo; a.out = out.p; a.out_lo_off = out.lo; a.out_f32 = out_f32;
     a.wpack = L.wpack; a.scale = L.scale; a.shift = L.shift;
-    a.w3 = c->w3; a.scale3 = c->scale3; a.shift3 = c->shift3;
+    a.w3 = c->w3; a.scale3 = c->scale3; a.shift3 = c->shift3; a.zero_page = c->zero_page;
     a.wsplit_stride = L.wsplit_stride;
     a.in_cs = in_cs; a.out_cs = out_cs; a.out_coff = out_coff; a.out_cp = out_cp;
     a.D = D;
     a.tiles_x = (D + C::TX - 1) / C::TX; a.tiles_y = (D + C::TY - 1) / C::TY; a.tiles_z = (D + C::TZ - 1) / C::TZ;
+    a.total_tiles = B * a.tiles_x * a.tiles_y * a.tiles_z;
     a.act = L.act;
     a.nslab = (int)L.slab_c8.size();
     for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
     const double vox = (double)B * D * D * D;
     const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : L.cout));
     ProfScope ps(c, L.name, 2.0 * L.macs_per_voxel * vox, bytes);
-    dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.tiles_z), (unsigned)L.nsplit);
-    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW>), grid, dim3(NW * 64), 0, c->stream, a);
+    // persistent workgroups: one resident set, each walking tiles blockIdx.x, +gridDim.x, ...
+    const int resident = std::max(1, c->num_cus * C::WG_PER_CU / L.nsplit);
+    dim3 grid((unsigned)std::min(a.total_tiles, resident), (unsigned)L.nsplit);
+    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV>), grid, dim3(NW * 64), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return SN_OK;
 }
@@ -324,6 +329,17 @@ static int launch_up(sn_ctx *c, const char *tag, Act in, Act cat, int B, int Di,
     return SN_OK;
 }
 
+template <int SPLIT>
+static int launch_up3(sn_ctx *c, Act s2, Act s3, Act s4, Act cat, int B, int Do, int cat_cs)
+{
+    const long long total = (long long)B * Do * Do * Do * 6;
+    ProfScope ps(c, "side_op234_deconv", 0, (double)B * Do * Do * Do * 48 * 2.0 * (SPLIT ? 2 : 1));
+    hipLaunchKernelGGL((upsample3_cat_kernel<SPLIT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, s2.p, s3.p, s4.p,
+                       cat.p, Do, cat_cs, total, s2.lo, s3.lo, s4.lo, cat.lo);
+    HIPCHK(hipGetLastError());
+    return SN_OK;
+}
+
 // x0 [S][s^3][8] fp16 -> unf [S][s^3] fp32 surface probabilities (nets/SurfaceNet.py:18-76).
 // Kernel configurations <KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH> per layer family; LDS budgets in DESIGN.md.
 template <int SP>
@@ -338,13 +354,13 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
               ma = A(c->ma, v1, 104), none = Act{nullptr, 0};
     int rc;
 #define RUN(x) do { if ((rc = (x)) != SN_OK) return rc; } while (0)
-#define CONV1 3, 1, (SP ? 4 : 8), 2, EPI_STORE, SP, (SP ? 2 : 4), (SP ? 4 : 8), (SP ? 8 : 4)
-#define SIDE  1, 1, 4, 1, EPI_STORE, SP, 10, (SP ? 8 : 16), 4
-#define CONV2 3, 1, 4, 5, EPI_STORE, SP, (SP ? 2 : 4), (SP ? 2 : 3), (SP ? 8 : 4)
-#define CONV3 3, 1, 4, 10, EPI_STORE, SP, 4, (SP ? 1 : 2), 4
-#define CONV4 3, 2, 4, 10, EPI_STORE, SP, (SP ? 2 : 4), (SP ? 1 : 2), 4
-#define MERGA 3, 1, 4, 7, EPI_STORE, SP, (SP ? 1 : 4), (SP ? 1 : 2), 4
-#define MERGB 3, 1, 4, 7, EPI_FINAL, SP, (SP ? 1 : 4), (SP ? 1 : 2), 4
+#define CONV1 3, 1, 4, 2, EPI_STORE, SP, 1, 7, 8, 0
+#define SIDE  1, 1, 4, 1, EPI_STORE, SP, 5, 2, 4, 0
+#define CONV2 3, 1, 4, 5, EPI_STORE, SP, 2, 1, 8, 0
+#define CONV3 3, 1, 4, 5, EPI_STORE, SP, 2, 1, 8, 0
+#define CONV4 3, 2, 4, 5, EPI_STORE, SP, 1, 2, 8, 0
+#define MERGA 3, 1, 4, 7, EPI_STORE, SP, 1, 2, 8, 0
+#define MERGB 3, 1, 4, 7, EPI_FINAL, SP, 1, 2, 8, 0
     auto &L = c->conv;
     RUN((launch_conv<CONV1>(c, L["conv1_1"], x0, 8, a1, 32, 0, 32, nullptr, S, s)));
     RUN((launch_conv<CONV1>(c, L["conv1_2"], a1, 32, b1, 32, 0, 32, nullptr, S, s)));
@@ -355,18 +371,16 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     RUN((launch_conv<CONV2>(c, L["conv2_2"], a2, 80, b2, 80, 0, 80, nullptr, S, D2)));
     RUN((launch_conv<CONV2>(c, L["conv2_3"], b2, 80, a2, 80, 0, 80, nullptr, S, D2)));
     RUN((launch_conv<SIDE>(c, L["side_op2"], a2, 80, s2, 16, 0, 16, nullptr, S, D2)));
-    RUN((launch_up<2, SP>(c, "side_op2_deconv", s2, cat, S, D2, 64, 16)));
     RUN((launch_pool<SP>(c, "pool2", a2, p2, S, D2, 80)));
     RUN((launch_conv<CONV3>(c, L["conv3_1"], p2, 80, a3, 160, 0, 160, nullptr, S, D3)));
     RUN((launch_conv<CONV3>(c, L["conv3_2"], a3, 160, b3, 160, 0, 160, nullptr, S, D3)));
     RUN((launch_conv<CONV3>(c, L["conv3_3"], b3, 160, a3, 160, 0, 160, nullptr, S, D3)));
     RUN((launch_conv<SIDE>(c, L["side_op3"], a3, 160, s3, 16, 0, 16, nullptr, S, D3)));
-    RUN((launch_up<4, SP>(c, "side_op3_deconv", s3, cat, S, D3, 64, 32)));
     RUN((launch_conv<CONV4>(c, L["conv4_1"], a3, 160, a4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<CONV4>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<CONV4>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<SIDE>(c, L["side_op4"], a4, 304, s4, 16, 0, 16, nullptr, S, D3)));
-    RUN((launch_up<4, SP>(c, "side_op4_deconv", s4, cat, S, D3, 64, 48)));
+    RUN((launch_up3<SP>(c, s2, s3, s4, cat, S, s, 64)));
     RUN((launch_conv<MERGA>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
     RUN((launch_conv<MERGB>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
 #undef RUN
@@ -427,6 +441,8 @@ static int create_impl(sn_ctx *c)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(SN_ERR_STATE, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    { unsigned char *z = nullptr; int rz = dev_alloc(c, &z, 4096); if (rz != SN_OK) return rz; HIPCHK(hipMemset(z, 0, 4096)); c->zero_page = z; }
     const size_t S = (size_t)c->max_samples, s = (size_t)c->s;
     const size_t v1 = s * s * s;
     int rc;
