@@ -96,6 +96,14 @@ int sn_cvc_forward(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, cons
  * features (n*n_vp, 258) float32 -> softmax weights (n, n_vp). */
 int sn_relative_weights(sn_ctx *ctx, int n, int n_vp, const float *features, float *weights);
 
+/* utils.generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42; call at main_reconstruct.py:150-152), float32 op for
+ * op: cvc (n*n_vp,6,s,s,s) is the MEAN-SUBTRACTED tensor of sn_cvc_forward (the caller's `X += mean` is applied inside);
+ * unfused (n,n_vp,s,s,s), w (n,n_vp) -> rgb (n,3,s,s,s) uint8. */
+int sn_color_fuse(sn_ctx *ctx, int n, int n_vp, const float *cvc, const float *mean6, const float *unfused, const float *w,
+                  unsigned char *rgb);
+int sn_color_fuse_dev(sn_ctx *ctx, int n, int n_vp, const float *cvc_dev, const float *mean6, const float *unfused_dev,
+                      const float *w_dev, unsigned char *rgb_dev);
+
 /* ---- hot path, device-resident (asynchronous on the context's stream) ------------------------- */
 void *sn_dev_alloc(sn_ctx *ctx, size_t bytes);
 int sn_dev_free(sn_ctx *ctx, void *p_dev);

@@ -95,3 +95,24 @@ def gen_non0Batch_npBool(boolIndicators, batch_size):
         end = min(start + batch_size, n_all)
         sel.append((cs >= start + 1) & (cs <= end) & ind)
     return np.array(sel)
+
+
+def color_fuse(viewPair_coloredCubes, viewPair_surf_predictions, weight4viewPair):
+    """utils/utils.py:8-42 generate_voxelLevelWeighted_coloredCubes restated op by op in float32:
+    vw = w*pred; vw /= sum_p vw; mc = mean over the pair's two views; rgb = uint8(sum_p vw*mc)."""
+    pred = np.asarray(viewPair_surf_predictions, dtype=np.float32)
+    n, P, D = pred.shape[:3]
+    w = np.asarray(weight4viewPair, dtype=np.float32)
+    X = np.asarray(viewPair_coloredCubes, dtype=np.float32).reshape(n, P, 2, 3, D, D, D)
+    vw = np.empty_like(pred)
+    for p in range(P):
+        vw[:, p] = w[:, p, None, None, None] * pred[:, p]
+    tot = np.zeros((n, D, D, D), dtype=np.float32)
+    for p in range(P):
+        tot = tot + vw[:, p]
+    out = np.zeros((n, 3, D, D, D), dtype=np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for p in range(P):
+            mc = (X[:, p, 0] + X[:, p, 1]) / np.float32(2)
+            out = out + (vw[:, p] / tot)[:, None] * mc
+        return np.nan_to_num(out, nan=0.0).astype(np.uint8)

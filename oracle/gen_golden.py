@@ -15,6 +15,7 @@ Fixtures written (all consumed by tests/, never by the product):
   proj_cases.npz   camera.perspectiveProj (camera.py:123-184) float + rounded outputs, incl. the
                    doctest inputs of camera.py:144-160
   batch_cases.npz  utils.gen_non0Batch_npBool (utils/utils.py:77-110) selectors
+  color_cases.npz  utils.generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42) output
 
 Usage:  python oracle/gen_golden.py   (from the repo root)
 """
@@ -139,6 +140,19 @@ def main():
         b["c%d/bs" % i] = np.asarray(bs)
         b["c%d/sel" % i] = np.asarray(sel, dtype=bool)
     np.savez(os.path.join(OUT, "batch_cases.npz"), **b)
+
+    # ---------------- voxel-level colour fusion (utils/utils.py:8-42; call site main_reconstruct.py:150-152) -------
+    rs = np.random.RandomState(9)
+    Nc, Np, D = 3, 2, 8
+    cvc_raw = cases["dtu_s8_vp1/out_u8"].astype(np.float32)[:0]          # shape only
+    col = rs.randint(0, 256, (Nc * Np, 6, D, D, D)).astype(np.float32)
+    X = col - MEAN6[None, :, None, None, None]
+    X += MEAN6[None, :, None, None, None]                                  # exactly what the caller holds at :150
+    pred = rs.rand(Nc, Np, D, D, D).astype(np.float32)
+    wgt = (rs.rand(Nc, Np) + 0.05).astype(np.float32)
+    rgb = ref_utils.generate_voxelLevelWeighted_coloredCubes(viewPair_coloredCubes=X, viewPair_surf_predictions=pred,
+                                                             weight4viewPair=wgt)
+    np.savez_compressed(os.path.join(OUT, "color_cases.npz"), col_u8=col.astype(np.uint8), pred=pred, w=wgt, rgb=rgb)
 
     for m in meta:
         print("case %-18s out %s in-scope fraction %.4f" % m)

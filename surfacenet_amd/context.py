@@ -133,6 +133,19 @@ class Context(object):
         _lib.check(self._lib.sn_relative_weights(self._h, n, n_vp, _lib.ptr(f), _lib.ptr(out)))
         return out
 
+    def color_fuse(self, cvc_minus_mean, unfused, w, mean=MEAN_CVC_RGBRGB):
+        """utils.generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42): (n,3,s,s,s) uint8 fused colours from the
+        mean-subtracted CVC tensor (n*n_vp,6,s,s,s), the unfused predictions (n,n_vp,s,s,s) and the pair weights (n,n_vp)."""
+        s = self.cube_D
+        unfused = np.ascontiguousarray(unfused, dtype=np.float32)
+        n, n_vp = unfused.shape[:2]
+        cvc = np.ascontiguousarray(cvc_minus_mean, dtype=np.float32).reshape(n * n_vp, 6, s, s, s)
+        w = np.ascontiguousarray(w, dtype=np.float32).reshape(n, n_vp)
+        m = np.ascontiguousarray(mean, dtype=np.float32).reshape(6)
+        rgb = np.empty((n, 3, s, s, s), dtype=np.uint8)
+        _lib.check(self._lib.sn_color_fuse(self._h, n, n_vp, _lib.ptr(cvc), _lib.ptr(m), _lib.ptr(unfused), _lib.ptr(w), _lib.ptr(rgb)))
+        return rgb
+
     # ---- hot path, device-resident ------------------------------------------------------------------
     def dev_alloc(self, nbytes):
         p = self._lib.sn_dev_alloc(self._h, int(nbytes))

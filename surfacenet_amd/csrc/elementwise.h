@@ -196,6 +196,38 @@ __global__ void __launch_bounds__(256) fuse_kernel(const float *unfused, const f
     fused[idx] = acc;
 }
 
+// Voxel-level colour fusion, generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42; main_reconstruct.py:150-152),
+// float32 op for op: vw = w*pred; vw /= sum_p vw; mc = ((x_a+mean) + (x_b+mean))/2; rgb = uint8(sum_p vw*mc).
+// cvc (n*n_vp, 6, s3) is the MEAN-SUBTRACTED tensor the hot path produced (the caller's `X += mean` happens here).
+__global__ void __launch_bounds__(256) color_fuse_kernel(const float *cvc, const float *unfused, const float *w, unsigned char *rgb,
+                                                         int n_vp, int s3, long long total, float m0, float m1, float m2, float m3,
+                                                         float m4, float m5)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long cube = idx / s3;
+    const int vox = (int)(idx - cube * s3);
+    const float mean[6] = {m0, m1, m2, m3, m4, m5};
+    float tot = 0.f;
+    for (int p = 0; p < n_vp; ++p) tot = tot + __fmul_rn(w[cube * n_vp + p], unfused[(cube * n_vp + p) * s3 + vox]);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int p = 0; p < n_vp; ++p) {
+        const float vw = __fdiv_rn(__fmul_rn(w[cube * n_vp + p], unfused[(cube * n_vp + p) * s3 + vox]), tot);
+        const float *x = cvc + ((cube * n_vp + p) * 6) * (long long)s3 + vox;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = __fadd_rn(x[(long long)c * s3], mean[c]), b = __fadd_rn(x[(long long)(c + 3) * s3], mean[c + 3]);
+            const float mc = __fdiv_rn(__fadd_rn(a, b), 2.0f);
+            acc[c] = __fadd_rn(acc[c], __fmul_rn(vw, mc));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = acc[c];
+        rgb[(cube * 3 + c) * s3 + vox] = (v == v) ? (unsigned char)(int)v : (unsigned char)0;   // NaN (all weights 0) -> 0
+    }
+}
+
 // Relative-weight MLP: one block (128 threads) per feature row. W1 (258,100) row-major fp32.
 __global__ void __launch_bounds__(128) relw_mlp_kernel(const float *feat, const float *W1, const float *scale1, const float *shift1,
                                                        const float *w2, float b2, float *z, int d_in, int n_hidden)

@@ -841,6 +841,49 @@ int sn_relative_weights(sn_ctx *c, int n, int n_vp, const float *features, float
     return SN_OK;
 }
 
+// utils.generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42) on device-resident tensors
+int sn_color_fuse_dev(sn_ctx *c, int n, int n_vp, const float *cvc_dev, const float *mean6, const float *unfused_dev,
+                      const float *w_dev, unsigned char *rgb_dev)
+{
+    if (!c || !cvc_dev || !unfused_dev || !w_dev || !rgb_dev) return fail(SN_ERR_ARG, "null argument");
+    if (n < 1 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
+    HIPCHK(hipSetDevice(c->device));
+    static const float kVggMean[6] = {123.68f, 116.779f, 103.939f, 123.68f, 116.779f, 103.939f};
+    const float *m = mean6 ? mean6 : kVggMean;
+    const int s3 = c->s * c->s * c->s;
+    const long long total = (long long)n * s3;
+    ProfScope ps(c, "color_fuse", 0, (double)total * (n_vp * 28.0 + 3.0));
+    hipLaunchKernelGGL(color_fuse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, cvc_dev, unfused_dev, w_dev,
+                       rgb_dev, n_vp, s3, total, m[0], m[1], m[2], m[3], m[4], m[5]);
+    HIPCHK(hipGetLastError());
+    return SN_OK;
+}
+
+int sn_color_fuse(sn_ctx *c, int n, int n_vp, const float *cvc, const float *mean6, const float *unfused, const float *w,
+                  unsigned char *rgb)
+{
+    if (!c || !cvc || !unfused || !w || !rgb) return fail(SN_ERR_ARG, "null argument");
+    if (n < 0 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
+    if (n == 0) return SN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t s3 = (size_t)c->s * c->s * c->s;
+    float *d_c = nullptr, *d_u = nullptr, *d_wt = nullptr; unsigned char *d_r = nullptr;
+    hipError_t e = hipMalloc((void **)&d_c, sizeof(float) * 6 * s3 * n * n_vp);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_u, sizeof(float) * s3 * n * n_vp);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_wt, sizeof(float) * n * n_vp);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_r, 3 * s3 * n);
+    int rc = SN_OK;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c, cvc, sizeof(float) * 6 * s3 * n * n_vp, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_u, unfused, sizeof(float) * s3 * n * n_vp, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_wt, w, sizeof(float) * n * n_vp, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) rc = sn_color_fuse_dev(c, n, n_vp, d_c, mean6, d_u, d_wt, d_r);
+    if (e == hipSuccess && rc == SN_OK) e = hipMemcpyAsync(rgb, d_r, 3 * s3 * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_c); (void)hipFree(d_u); (void)hipFree(d_wt); (void)hipFree(d_r);
+    if (e != hipSuccess) return fail(SN_ERR_HIP, "sn_color_fuse: %s", hipGetErrorString(e));
+    return rc;
+}
+
 // ---- raw device memory helpers (for hosts without a GPU array library) -------------------------------
 void *sn_dev_alloc(sn_ctx *c, size_t bytes)
 {

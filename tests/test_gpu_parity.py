@@ -109,3 +109,71 @@ def test_cvc_forward_fused_path(sn, precision):
     f64, u64 = net_oracle.forward_torch(ref_cvc, values, w=sc["w"], n_vp=n_vp)
     tol = TOL_X3 if precision == "f16x3" else TOL_F16
     assert np.abs(unfused - u64).max() < tol and np.abs(fused - f64).max() < tol
+
+
+def test_forward_s64_vs_oracle(sn):
+    """BASELINE config 4 cube size: s=64 (activation workspace 8x the s=32 one, 512 tiles per sample)."""
+    from oracle import net_oracle
+    values, X, _ = _net_case(64, 1, 1, seed=64)
+    with sn.Context(cube_D=64, max_samples=2) as ctx:
+        ctx.load_param_values(values)
+        fused, unfused = ctx.forward(X, None, n_vp=1)
+    f32, u32 = net_oracle.forward_torch(X, values, n_vp=1, dtype="float32")     # fp32 oracle: fp64 at s=64 takes minutes
+    err = np.abs(unfused - u32).max()
+    print("s=64 f16x3: L_inf vs fp32 oracle %.3e" % err)
+    assert err < TOL_X3
+
+
+def test_full_batch_properties(sn):
+    """BASELINE config 2 size (s=32, 64 cubes x 2 view pairs): size-independent properties of the hot path."""
+    import synth
+    from oracle import cvc_oracle
+    s, n, n_vp = 32, 64, 2
+    sc = golden_util.synthetic_scene(n, n_vp, s=s, seed=11)
+    values = list(synth.calibrated_params(2))
+    with sn.Context(cube_D=s, max_samples=n * n_vp) as ctx:
+        ctx.load_param_values(values)
+        ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        fused, unfused, cvc = ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"], sc["w"], return_cvc=True)
+        # (1) CVC: the sampled cubes are bit-exact vs the oracle
+        idx = [0, 17, 63]
+        ref = cvc_oracle.gen_coloredCubes(sc["pairs"][idx], sc["xyz"][idx], sc["resol"][idx], sc["cams"], sc["imgs"], s, mean6=golden_util.MEAN6)
+        got = cvc.reshape(n, n_vp, 6, s, s, s)[idx].reshape(-1, 6, s, s, s)
+        assert np.array_equal(got, ref)
+        # (2) fusion renormalises the weights (nets/layers.py:330-331): scaling w changes nothing beyond fp32 rounding
+        f2, _, _ = ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"], 4.0 * sc["w"])
+        assert np.abs(f2 - fused).max() < 1e-6
+        # (3) the fused output is the normalised weighted mean of the unfused ones
+        cw = sc["w"] / sc["w"].sum(axis=1, keepdims=True)
+        assert np.abs((unfused * cw[:, :, None, None, None]).sum(axis=1, keepdims=True) - fused).max() < 1e-6
+        # (4) cubes are independent: any sub-batch / permutation reproduces the same bits (what the multi-GPU sharding relies on)
+        perm = np.random.RandomState(0).permutation(n)[:9]
+        f3, u3, _ = ctx.cvc_forward(sc["pairs"][perm], sc["xyz"][perm], sc["resol"][perm], sc["w"][perm])
+        assert np.array_equal(f3, fused[perm]) and np.array_equal(u3, unfused[perm])
+        # (5) probabilities are probabilities, and a pair (a,b) vs (b,a) is a different input (channel order matters)
+        assert fused.min() > 0.0 and fused.max() < 1.0 and np.isfinite(unfused).all()
+
+
+def test_color_fusion_bit_exact_vs_reference_golden(sn):
+    import os
+    z = np.load(os.path.join(golden_util.GOLDEN, "color_cases.npz"))
+    X = z["col_u8"].astype(np.float32) - golden_util.MEAN6[None, :, None, None, None]      # what sn_cvc_forward returns as cvc_out
+    with sn.Context(cube_D=8, max_samples=8) as ctx:
+        rgb = ctx.color_fuse(X, z["pred"], z["w"])
+    assert rgb.dtype == np.uint8 and np.array_equal(rgb, z["rgb"])
+
+
+def test_relative_weight_mlp_vs_oracle(sn):
+    from oracle import net_oracle
+    from surfacenet_amd import weights
+    values = weights.synthetic_param_values(4)
+    f = np.random.RandomState(4).rand(7 * 5, 258).astype(np.float32)
+    with sn.Context(cube_D=8, max_samples=4) as ctx:
+        ctx.load_param_values(values)
+        got = ctx.relative_weights(f, 5)
+    ref = net_oracle.relative_weights(f, values, 5)
+    assert got.shape == (7, 5) and np.abs(got - ref).max() < 1e-5 and np.allclose(got.sum(axis=1), 1.0, atol=1e-5)
+    with sn.Context(cube_D=8, max_samples=4) as ctx:
+        ctx.load_param_values(values[:98])                       # network-only weight list: the MLP is unavailable
+        with pytest.raises(sn.SurfaceNetHipError):
+            ctx.relative_weights(f, 5)

@@ -83,3 +83,11 @@ def test_batch_selector_goldens():
     for i in range(5):
         sel = cvc_oracle.gen_non0Batch_npBool(z["c%d/ind" % i], int(z["c%d/bs" % i]))
         assert np.array_equal(sel, z["c%d/sel" % i])
+
+
+def test_color_fusion_golden():
+    z = np.load(os.path.join(golden_util.GOLDEN, "color_cases.npz"))
+    X = z["col_u8"].astype(np.float32) - golden_util.MEAN6[None, :, None, None, None]
+    X += golden_util.MEAN6[None, :, None, None, None]                 # what the caller holds at main_reconstruct.py:150
+    rgb = cvc_oracle.color_fuse(X, z["pred"], z["w"])
+    assert rgb.dtype == np.uint8 and np.array_equal(rgb, z["rgb"])
