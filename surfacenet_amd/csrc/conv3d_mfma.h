@@ -6,9 +6,10 @@
 //   batch_norm(...) at deterministic=True folded to y = act(conv*scale + shift)
 //   merge_conv3 (1x1x1, 100 -> 1, BN, sigmoid) fused as a second epilogue (nets/SurfaceNet.py:74)
 //
-// Data layout (ours, not the reference's NCDHW): activations are channels-last fp16
-//   act[b][x][y][z][c], c padded to a multiple of 8, so one voxel's 8-channel group is one 16-byte
-//   vector = exactly one lane's share of a v_mfma_f32_16x16x32_f16 B operand.
+// Data layout (ours, not the reference's NCDHW): activations are fp16 in 8-channel groups,
+//   act[b][c/8][x][y][z][c%8] (c padded to a multiple of 8): one voxel's group is one 16-byte vector = exactly one
+//   lane's share of a v_mfma_f32_16x16x32_f16 B operand, and one channel slab of a halo tile is a set of contiguous
+//   z-rows in HBM (the LDS-DMA that stages it reads whole cache lines instead of 16-byte slivers).
 // Precision modes (template SPLIT):
 //   SPLIT=0  "f16":   operands rounded to fp16, fp32 accumulate. L_inf vs the fp64 oracle ~2e-3 on
 //                     BN-calibrated nets -> does NOT meet the 1e-3 parity bar; offered as the fast mode.
@@ -58,8 +59,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxSlab = 48;
 
 struct ConvArgs {
-    const _Float16 *in;   // [B][D][D][D][in_cs]  (hi plane; lo plane at +in_lo_off elements when SPLIT)
-    _Float16 *out;        // [B][D][D][D][out_cs] (+ out_coff)
+    const _Float16 *in;   // [B][in_cs/8][D][D][D][8]  (hi plane; lo plane at +in_lo_off elements when SPLIT)
+    _Float16 *out;        // [B][out_cs/8][D][D][D][8], channels [out_coff, out_coff+out_cp)
     float *out_f32;       // EPI_FINAL: [B][D][D][D]
     const _Float16 *wpack;
     const float *scale;   // [nsplit*NF*16]
@@ -201,7 +202,7 @@ conv3d_f16_mfma(ConvArgs a)
             const int gx = x0 - C::R + hx, gy = y0 - C::R + hy, gz = z0 - C::R + hz;
             const bool ok = part < c8n && hv < C::HVOX && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D &&
                             (unsigned)gz < (unsigned)D;
-            const _Float16 *p = in_b + ((size_t)(gx * D + gy) * D + gz) * a.in_cs + (c0 + part) * 8 + (pl ? a.in_lo_off : 0);
+            const _Float16 *p = in_b + ((size_t)(c0 + part) * D * D * D + ((size_t)(gx * D + gy) * D + gz)) * 8 + (pl ? a.in_lo_off : 0);
             dma16<SN_HALO_AUX>(ok ? (const void *)p : a.zero_page, xbuf + xb * C::XBUF + pl * C::XPLANE + seg * 1024);
             ++issued;
         }
@@ -409,7 +410,7 @@ conv3d_f16_mfma(ConvArgs a)
             for (int m = 0; m < MF; ++m) {
                 const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
                 const bool valid = gx < D && gy < D && gz < D;
-                const size_t vox = ((size_t)(b * D + gx) * D + gy) * D + gz;
+                const size_t vlin = ((size_t)gx * D + gy) * D + gz;
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
@@ -427,7 +428,8 @@ conv3d_f16_mfma(ConvArgs a)
                                 h[r] = hh; l[r] = ll;
                             } else h[r] = (_Float16)y;
                         }
-                        _Float16 *o = a.out + vox * a.out_cs + a.out_coff + nl;
+                        const int ch = a.out_coff + nl;   // group-blocked layout: [b][ch/8][x][y][z][ch%8]
+                        _Float16 *o = a.out + (size_t)b * D * D * D * a.out_cs + ((size_t)(ch >> 3) * D * D * D + vlin) * 8 + (ch & 7);
                         *reinterpret_cast<half4 *>(o) = h;
                         if constexpr (SPLIT) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
                     }

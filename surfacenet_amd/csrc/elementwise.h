@@ -1,8 +1,8 @@
 // elementwise.h — the HBM-bound glue ops of the SurfaceNet graph on channels-last fp16 tensors.
 //   maxpool2_kernel      Pool3DDNNLayer((2,2,2), stride=2)                 nets/SurfaceNet.py:37,46
-//   upsample_cat_kernel  Bilinear_3DInterpolation (zero-insert + fixed k^3 conv, closed form of
-//                        SURVEY App. D) written straight into its channel block of the
-//                        ConcatLayer buffer                                nets/layers.py:363-390, SurfaceNet.py:71
+//   upsample3_cat_kernel Bilinear_3DInterpolation x3 (zero-insert + fixed k^3 conv, closed form of SURVEY App. D)
+//                        written straight into their channel groups of the ConcatLayer buffer
+//                                                                          nets/layers.py:363-390, SurfaceNet.py:71
 //   fuse_kernel          ChannelPool_weightedAverage over the view pairs   nets/layers.py:325-336
 //   relw_*               the relative-weight MLP + grouped softmax         nets/SurfaceNet.py:84-100
 #pragma once
@@ -13,7 +13,7 @@ namespace sn {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-// in [B][D][D][D][C] -> out [B][D/2][D/2][D/2][C]; one thread = one output voxel x 8 channels.
+// in [B][C/8][D][D][D][8] -> out [B][C/8][D/2][D/2][D/2][8]; one thread = one output voxel of one 8-channel group.
 // SPLIT: values are hi+lo pairs of fp16 planes (lo plane at +lo_off elements); the max is taken on hi+lo.
 template <int SPLIT>
 __global__ void __launch_bounds__(256) maxpool2_kernel(const _Float16 *in, _Float16 *out, int D, int C, long long total,
@@ -22,13 +22,14 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const _Float16 *in, _Floa
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c8n = C >> 3, Do = D >> 1;
-    const int c8 = (int)(idx % c8n);
-    long long t = idx / c8n;
+    long long t = idx;
     const int z = (int)(t % Do); t /= Do;
     const int y = (int)(t % Do); t /= Do;
-    const int x = (int)(t % Do);
-    const long long b = t / Do;
-    const _Float16 *p = in + ((((b * D + 2 * x) * D + 2 * y) * D + 2 * z) * (long long)C) + c8 * 8;
+    const int x = (int)(t % Do); t /= Do;
+    const int c8 = (int)(t % c8n);
+    const long long b = t / c8n;
+    // group-blocked layout [b][c8][x][y][z][8]
+    const _Float16 *p = in + (((b * c8n + c8) * D + 2 * x) * D + 2 * y) * (long long)D * 8 + 2 * z * 8;
     h8 m = *reinterpret_cast<const h8 *>(p), ml;
     float mv[8];
     if constexpr (SPLIT) {
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const _Float16 *in, _Floa
     }
 #pragma unroll
     for (int o = 1; o < 8; ++o) {
-        const _Float16 *pq = p + ((long long)((o >> 2) * D + ((o >> 1) & 1)) * D + (o & 1)) * C;
+        const _Float16 *pq = p + ((long long)((o >> 2) * D + ((o >> 1) & 1)) * D + (o & 1)) * 8;
         const h8 q = *reinterpret_cast<const h8 *>(pq);
         if constexpr (SPLIT) {
             const h8 ql = *reinterpret_cast<const h8 *>(pq + in_lo_off);
@@ -74,60 +75,10 @@ __device__ __forceinline__ void up_axis(int o, int n_in, int &m, float &wa, floa
     if (m + 1 >= n_in) wb = 0.f;
 }
 
-// in [B][Di][Di][Di][16] -> cat [B][Do][Do][Do][cat_cs] channels [coff, coff+16), Do = F*Di.
-// One thread = one output voxel x 8 channels. SPLIT: hi/lo fp16 planes in and out.
-template <int F, int SPLIT>
-__global__ void __launch_bounds__(256) upsample_cat_kernel(const _Float16 *in, _Float16 *cat, int Di, int cat_cs, int coff,
-                                                           long long total, long long in_lo_off, long long out_lo_off)
-{
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int Do = Di * F;
-    const int c8 = (int)(idx & 1);
-    long long t = idx >> 1;
-    const int z = (int)(t % Do); t /= Do;
-    const int y = (int)(t % Do); t /= Do;
-    const int x = (int)(t % Do);
-    const long long b = t / Do;
-    int mx, my, mz;
-    float ax, bx, ay, by, az, bz;
-    up_axis<F>(x, Di, mx, ax, bx);
-    up_axis<F>(y, Di, my, ay, by);
-    up_axis<F>(z, Di, mz, az, bz);
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        const int dx = o >> 2, dy = (o >> 1) & 1, dz = o & 1;
-        const float w = (dx ? bx : ax) * (dy ? by : ay) * (dz ? bz : az);
-        if (w != 0.f) {
-            const _Float16 *pq = in + ((((b * Di + mx + dx) * Di + my + dy) * Di + mz + dz) * 16LL) + c8 * 8;
-            const h8 q = *reinterpret_cast<const h8 *>(pq);
-            if constexpr (SPLIT) {
-                const h8 ql = *reinterpret_cast<const h8 *>(pq + in_lo_off);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w * ((float)q[e] + (float)ql[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w * (float)q[e];
-            }
-        }
-    }
-    h8 r, rl;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        r[e] = (_Float16)acc[e];
-        if constexpr (SPLIT) rl[e] = (_Float16)(acc[e] - (float)r[e]);
-    }
-    _Float16 *o = cat + ((((b * Do + x) * Do + y) * Do + z) * (long long)cat_cs) + coff + c8 * 8;
-    *reinterpret_cast<h8 *>(o) = r;
-    if constexpr (SPLIT) *reinterpret_cast<h8 *>(o + out_lo_off) = rl;
-}
-
 // All three upsampled side outputs of one voxel in one pass: cat[...][16..63] = [up2(s2) | up4(s3) | up4(s4)], i.e. the 96
 // contiguous bytes (per plane) that follow side_op1's 16 channels in the ConcatLayer buffer (nets/SurfaceNet.py:71).
-// One thread = one output voxel x one 8-channel group (6 groups per voxel -> 6 consecutive threads write one 96-byte run).
+// One thread = one output voxel of one of the 6 destination 8-channel groups (consecutive threads = consecutive z:
+// fully coalesced 16-byte stores in the group-blocked layout [b][group][x][y][z][8]).
 template <int SPLIT>
 __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, const _Float16 *s3, const _Float16 *s4, _Float16 *cat,
                                                             int Do, int cat_cs, long long total, long long lo2, long long lo3,
@@ -135,12 +86,12 @@ __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, 
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int g = (int)(idx % 6);
-    long long t = idx / 6;
+    long long t = idx;
     const int z = (int)(t % Do); t /= Do;
     const int y = (int)(t % Do); t /= Do;
-    const int x = (int)(t % Do);
-    const long long b = t / Do;
+    const int x = (int)(t % Do); t /= Do;
+    const int g = (int)(t % 6);
+    const long long b = t / 6;
     const int src = g >> 1, c8 = g & 1;                 // 0: s2 (x2), 1: s3 (x4), 2: s4 (x4)
     const _Float16 *in = src == 0 ? s2 : (src == 1 ? s3 : s4);
     const long long in_lo = src == 0 ? lo2 : (src == 1 ? lo3 : lo4);
@@ -157,7 +108,7 @@ __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, 
         const int dx = o >> 2, dy = (o >> 1) & 1, dz = o & 1;
         const float w = (dx ? bx : ax) * (dy ? by : ay) * (dz ? bz : az);
         if (w != 0.f) {
-            const _Float16 *pq = in + ((((b * Di + mx + dx) * Di + my + dy) * Di + mz + dz) * 16LL) + c8 * 8;
+            const _Float16 *pq = in + (((((b * 2 + c8) * Di + mx + dx) * Di + my + dy) * Di + mz + dz) * 8LL);
             const h8 q = *reinterpret_cast<const h8 *>(pq);
             if constexpr (SPLIT) {
                 const h8 ql = *reinterpret_cast<const h8 *>(pq + in_lo);
@@ -175,7 +126,7 @@ __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, 
         r[e] = (_Float16)acc[e];
         if constexpr (SPLIT) rl[e] = (_Float16)(acc[e] - (float)r[e]);
     }
-    _Float16 *o = cat + ((((b * Do + x) * Do + y) * Do + z) * (long long)cat_cs) + 16 + g * 8;
+    _Float16 *o = cat + ((((b * (cat_cs >> 3) + 2 + g) * Do + x) * Do + y) * Do + z) * 8LL;
     *reinterpret_cast<h8 *>(o) = r;
     if constexpr (SPLIT) *reinterpret_cast<h8 *>(o + out_lo_off) = rl;
 }

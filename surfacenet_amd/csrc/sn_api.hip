@@ -317,18 +317,6 @@ static int launch_pool(sn_ctx *c, const char *tag, Act in, Act out, int B, int D
     return SN_OK;
 }
 
-template <int F, int SPLIT>
-static int launch_up(sn_ctx *c, const char *tag, Act in, Act cat, int B, int Di, int cat_cs, int coff)
-{
-    const int Do = Di * F;
-    const long long total = (long long)B * Do * Do * Do * 2;
-    ProfScope ps(c, tag, 0, (double)B * Do * Do * Do * 16 * 2.0 * (SPLIT ? 2 : 1));
-    hipLaunchKernelGGL((upsample_cat_kernel<F, SPLIT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, in.p, cat.p,
-                       Di, cat_cs, coff, total, in.lo, cat.lo);
-    HIPCHK(hipGetLastError());
-    return SN_OK;
-}
-
 template <int SPLIT>
 static int launch_up3(sn_ctx *c, Act s2, Act s3, Act s4, Act cat, int B, int Do, int cat_cs)
 {
