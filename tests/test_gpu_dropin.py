@@ -1,0 +1,96 @@
+"""GPU (-m gpu): the drop-in modules with the reference's own call signatures, written the way the
+reference's loop body (main_reconstruct.py:132-152) calls them."""
+import numpy as np
+import pytest
+
+import golden_util
+
+pytestmark = pytest.mark.gpu
+CASES = golden_util.cvc_cases()
+
+
+@pytest.fixture()
+def dropin(gpu_required):
+    from surfacenet_amd import CVC, SurfaceNet, runtime
+    runtime.reset()
+    yield CVC, SurfaceNet, runtime
+    runtime.reset()
+
+
+def test_gen_coloredCubes_keyword_call_matches_reference_golden(dropin):
+    CVC, _, _ = dropin
+    for name in ("dtu_s16_vp2", "mid_s16_vp2"):                # two scenes in a row: the cached scene must be re-bound
+        c = CASES[name]
+        imgs = golden_util.case_images(c)
+        out = CVC.gen_coloredCubes(selected_viewPairs=c["pairs"], xyz=c["xyz"], resol=c["resol"], colorize_cube_D=int(c["s"]),
+                                   cameraPOs=c["P"], models_img=imgs, visualization_ON=False)
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.flags.writeable
+        assert np.array_equal(out, c["out_u8"].astype(np.float32))
+    with pytest.raises(IndexError):                            # numpy raises IndexError in the reference
+        bad = c["pairs"].copy(); bad[0, 0, 0] = 99
+        CVC.gen_coloredCubes(bad, c["xyz"], c["resol"], c["P"], imgs, int(c["s"]))
+    empty = CVC.gen_coloredCubes(c["pairs"][:0], c["xyz"][:0], c["resol"][:0], c["P"], imgs, int(c["s"]))
+    assert empty.shape == (0, 6, 16, 16, 16)
+
+
+def test_loop_body_three_call_protocol(dropin):
+    """main_reconstruct.py:134-150 verbatim (names kept), N_viewPairs4inference = 2 and 1."""
+    CVC, SurfaceNet, runtime = dropin
+    import synth
+    from oracle import net_oracle
+    c = CASES["dtu_s16_vp2"]
+    cube_D = int(c["s"])
+    images_list, cameraPOs_np = golden_util.case_images(c), c["P"]
+    values = list(synth.calibrated_params(0))
+    MEAN = golden_util.MEAN6
+    for N_viewPairs4inference in (2, 1):
+        viewPair_relativeImpt_fn, nViewPair_SurfaceNet_fn = SurfaceNet.SurfaceNet_inference(
+            N_viewPairs4inference, model_file=None, layerNameList_2_load=["output_SurfaceNet_reshape", "output_softmaxWeights"],
+            cube_D=cube_D, param_values=values)
+        pairs = c["pairs"][:, :N_viewPairs4inference]
+        w = (np.random.RandomState(3).rand(pairs.shape[0], N_viewPairs4inference) + 0.1).astype(np.float32)
+        _CVCs1_sub = CVC.gen_coloredCubes(selected_viewPairs=pairs, xyz=c["xyz"], resol=c["resol"], colorize_cube_D=cube_D,
+                                          cameraPOs=cameraPOs_np, models_img=images_list, visualization_ON=False)
+        _, _CVCs2_sub = CVC.preprocess_augmentation(None, _CVCs1_sub, mean_rgb=MEAN[None, :, None, None, None], augment_ON=False, crop_ON=False)
+        surfacePrediction, unfused_predictions = nViewPair_SurfaceNet_fn(_CVCs2_sub) if N_viewPairs4inference == 1 \
+            else nViewPair_SurfaceNet_fn(_CVCs2_sub, w)
+        keep = _CVCs2_sub.copy()
+        _CVCs2_sub += MEAN[None, :, None, None, None]                   # :150 mutates the array in place
+        f64, u64 = net_oracle.forward_torch(keep, values, w=w, n_vp=N_viewPairs4inference)
+        assert surfacePrediction.shape == (pairs.shape[0], 1, cube_D, cube_D, cube_D)
+        assert np.abs(surfacePrediction - f64).max() < 1e-4 and np.abs(unfused_predictions - u64).max() < 1e-4
+        if N_viewPairs4inference == 1:
+            assert unfused_predictions is surfacePrediction or np.array_equal(unfused_predictions, surfacePrediction)
+            with pytest.raises(TypeError):
+                nViewPair_SurfaceNet_fn(_CVCs2_sub, w)
+        else:
+            with pytest.raises(TypeError):
+                nViewPair_SurfaceNet_fn(_CVCs2_sub.astype(np.float64), w)      # Theano rejects non-float32 input
+            sm = viewPair_relativeImpt_fn(np.random.RandomState(1).rand(6, 258).astype(np.float32), n_samples_perGroup=3)
+            assert sm.shape == (2, 3) and np.allclose(sm.sum(axis=1), 1, atol=1e-5)
+
+
+def test_hot_loop_matches_three_call_protocol(dropin):
+    """reconstruct.hot_loop (one fused call per batch) == the three-call protocol, batch partition of utils.gen_non0Batch_npBool."""
+    _, _, _ = dropin
+    import surfacenet_amd
+    import synth
+    from surfacenet_amd import reconstruct
+    s, n_all, n_vp = 16, 9, 2
+    validCubes = np.array([1, 1, 0, 1, 1, 1, 0, 1, 1], dtype=bool)
+    sc = golden_util.synthetic_scene(n_all, n_vp, s=s, seed=2, hw=(600, 800))
+    cubes_param_np = np.zeros(n_all, dtype=[("xyz", np.float32, (3,)), ("ijk", np.uint32, (3,)), ("resol", np.float32)])
+    cubes_param_np["xyz"], cubes_param_np["resol"] = sc["xyz"], sc["resol"]
+    viewPairs4Reconstr, w4 = sc["pairs"][validCubes], sc["w"][validCubes]          # indexed by valid cube, as in the reference
+    values = list(synth.calibrated_params(1))
+    with surfacenet_amd.Context(cube_D=s, max_samples=8) as ctx:
+        ctx.load_param_values(values); ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        seen = np.zeros(n_all, dtype=int)
+        for _batch, pred, unf, cvc_raw in reconstruct.hot_loop(ctx, validCubes, viewPairs4Reconstr, w4, cubes_param_np, batch_size=3):
+            sel = _batch[validCubes]
+            seen += _batch
+            raw = ctx.cvc(viewPairs4Reconstr[sel], cubes_param_np["xyz"][_batch], cubes_param_np["resol"][_batch])
+            assert np.abs(cvc_raw - raw).max() < 1e-4                                 # (raw - mean) + mean, fp32
+            f, u = ctx.forward(raw - golden_util.MEAN6[None, :, None, None, None], w4[sel], n_vp=n_vp)
+            assert np.array_equal(f, pred) and np.array_equal(u, unf)
+        assert np.array_equal(seen, validCubes.astype(int))                           # every valid cube exactly once
