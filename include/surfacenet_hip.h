@@ -63,6 +63,9 @@ int sn_synchronize(sn_ctx *ctx);
  * Call before sn_load_weights (weights are packed for the selected mode). */
 #define SN_PRECISION_F16 0
 #define SN_PRECISION_F16X3 1
+/*   SN_PRECISION_F16M8: main term on the f16 MFMA, the two 2^-11 correction terms on one MX-scaled fp8 MFMA
+ *       (v_mfma_scale_f32_16x16x128_f8f6f4): 2 MFMA units per product; L_inf ~1e-4 (bar 1e-3). */
+#define SN_PRECISION_F16M8 2
 int sn_set_precision(sn_ctx *ctx, int mode);
 int sn_get_precision(sn_ctx *ctx);
 

@@ -18,6 +18,10 @@
 //                     2^-22 relative), fp32 accumulate -> fp32-class results at 1/3 of the f16 MFMA rate,
 //                     still 5.3x the f32-input MFMA rate of gfx950 (no xf32/TF32 on this chip).
 //                     Activations live in HBM as two fp16 planes (hi, lo).
+//   SPLIT=2  "f16m8": the main term wh*xh on the f16 MFMA; the two correction terms wl*xh + wh*xl (2^-11 of it) on ONE
+//                     v_mfma_scale_f32_16x16x128_f8f6f4 per 64 k (fp8 e4m3 operands, lo parts pre-scaled by 2^12, the
+//                     2^-12 applied through the E8M0 block scale): 2 MFMA units per product instead of 3. L_inf vs the
+//                     fp64 oracle ~1e-4 (bar 1e-3). Second activation plane = [fp8(hi) x8 | fp8(lo*2^12) x8] per group.
 // GEMM view: D[cout][voxel] += W[cout][k] * X[k][voxel], k = (tap, cin) in 8-channel groups.
 //   A operand = weights, pre-packed on the host in fragment order (lane l: cout = l&15, k = (l>>4)*8 + j);
 //   B operand = activations of a (TX+2R)x(TY+2R)x(TZ+2R) halo tile, staged per channel slab in LDS and re-read
@@ -108,6 +112,25 @@ __device__ __forceinline__ void lds_read32(int &d, unsigned addr)
 {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
 }
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read64(long long &d, unsigned addr)
+{
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128i(v4i &d, unsigned addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+// fp8 e4m3 pack of four fp32 values (round-to-nearest-even, saturating at +-448)
+__device__ __forceinline__ int sn_pack_fp8x4(float a, float b, float c, float d)
+{
+    auto cl = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
+}
 template <int N>
 __device__ __forceinline__ void lgkm_wait()
 {
@@ -139,11 +162,14 @@ struct ConvCfg {
     static constexpr int SLOTS = CS8 + PADV_;              // 16-byte slots per halo voxel (PADV: one pad slot)
     static constexpr int VS = SLOTS * 16;                  // LDS bytes per halo voxel
     static constexpr int PCH = PCH_;                       // K-chunks per weight piece (one barrier per piece)
-    static constexpr int NPL = SPLIT ? 2 : 1;              // planes (hi, lo)
-    static constexpr int FRAG = 1024 * NPL;                // bytes of one packed weight fragment (hi [+ lo])
+    static constexpr int NPL = SPLIT ? 2 : 1;              // activation planes (hi [, lo | fp8 pair])
+    static constexpr int NPLM = SPLIT == 1 ? 2 : 1;        // planes the f16 main loop reads (f16x3: hi and lo)
+    static constexpr int FRAG = 1024 * NPL;                // weight bytes per (K-chunk, cout fragment)
+    static constexpr int MFRAG = 1024 * NPLM;              // bytes of one f16 weight fragment set (hi [+ lo])
+    static_assert(SPLIT != 2 || PCH_ == 2, "f16m8: a weight piece is 2 K-chunks + one MX step");
     static constexpr int WBUF = PCH * NF * FRAG;
     static constexpr int NTAP = KS * KS * KS;
-    static constexpr int KOFF_N = NTAP * CS8MAX + 12;      // + 2 chunks of look-ahead padding
+    static constexpr int KOFF_N = NTAP * CS8MAX + 20;      // + look-ahead padding (2 chunks; f16m8: one 8-group piece)
     static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
     static constexpr int XPLANE = NSEG * 1024;
     static constexpr int XBUF = XPLANE * NPL;
@@ -228,7 +254,7 @@ conv3d_f16_mfma(ConvArgs a)
     auto write_koff = [&](int c8n, int kb) {
         const int G = C::NTAP * c8n, nchunk = (G + 3) >> 2;
         int *k = kbuf + kb * C::KOFF_N;
-        for (int g = tid; g < (nchunk + 2) * 4; g += C::NT) {
+        for (int g = tid; g < (nchunk + 4) * 4; g += C::NT) {
             int o = 0;
             if (g < G) {
                 const int tap = g / c8n, c8 = g - tap * c8n;
@@ -246,6 +272,8 @@ conv3d_f16_mfma(ConvArgs a)
         for (int i = wave; i < cnt; i += C::NW) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
     };
     auto chunks_of = [&](int c8n) { return (C::NTAP * c8n + 3) >> 2; };
+    // K-chunks the weight STREAM holds for a slab (f16m8 pads every slab to whole pieces)
+    auto wchunks_of = [&](int c8n) { return SPLIT == 2 ? (((C::NTAP * c8n + 7) >> 3) << 1) : ((C::NTAP * c8n + 3) >> 2); };
 
     int xbase[MF];
 #pragma unroll
@@ -260,7 +288,7 @@ conv3d_f16_mfma(ConvArgs a)
         const int c8n = a.slab_c8[0];
         stage_halo(tile, 0, c8n, 0, 0, HT);
         write_koff(c8n, 0);
-        const int nch = chunks_of(c8n);
+        const int nch = wchunks_of(c8n);
         stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         wg_barrier();
@@ -291,7 +319,8 @@ conv3d_f16_mfma(ConvArgs a)
             const int nslab_i = last_slab ? 0 : slab + 1;
             const int nc8n = a.slab_c8[nslab_i];
             const int nc0 = last_slab ? 0 : c0 + c8n;
-            const size_t nwoff = last_slab ? 0 : woff + (size_t)nchunk * NF * C::FRAG;
+            const int wchunk = wchunks_of(c8n);
+            const size_t nwoff = last_slab ? 0 : woff + (size_t)wchunk * NF * C::FRAG;
             if (have_next) write_koff(nc8n, xb ^ 1);
             // the next halo tile is fetched in npiece-1 instalments, each issued right after a weight piece so that a
             // counted vmcnt can wait for the weights while the newest halo DMAs stay in flight
@@ -307,24 +336,28 @@ conv3d_f16_mfma(ConvArgs a)
             unsigned xaddr[MF];
 #pragma unroll
             for (int m = 0; m < MF; ++m) xaddr[m] = xbuf_a + xb * C::XBUF + (unsigned)xbase[m];
-            half8 xc[NPL][MF], xn[NPL][MF], wr[2][NPL];
+            constexpr int NPLM = C::NPLM;
+            half8 xc[NPLM][MF], xn[NPLM][MF], wr[2][NPLM];
             int ko1, ko2;
-            auto issue_x = [&](half8(&dst)[NPL][MF], int ko) {
+            auto issue_x = [&](half8(&dst)[NPLM][MF], int ko) {
                 if constexpr (SN_ABL & 32) return;
                 static_for<0, MF>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
                     const unsigned ad = xaddr[m] + (unsigned)ko;
                     lds_read128<0>(dst[0][m], ad);
-                    if constexpr (SPLIT) {
+                    if constexpr (SPLIT == 1) {
                         if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(dst[1][m], ad);
                         else lds_read128<0>(dst[1][m], ad + C::XPLANE);
                     }
                 });
             };
+            v4i k4, k4n;                                                      // f16m8: tap offsets of the MX step's 4 groups
+            const unsigned k4_a = koff_a - kq * 4 + (unsigned)(4 * (kq & 1)) * 4;
             {
                 int k0;
                 lds_read32<0>(k0, koff_a);
                 lds_read32<16>(ko1, koff_a);
+                if constexpr (SPLIT == 2) lds_read128i<0>(k4, k4_a);
                 lgkm_wait<0>();
                 issue_x(xc, k0);
                 lgkm_wait<0>();
@@ -333,14 +366,17 @@ conv3d_f16_mfma(ConvArgs a)
                 const int ch0 = p * C::PCH;
                 // first weight fragment of this piece: issue its LDS read before the (VALU-heavy) DMA address work
                 const unsigned wp = wbuf_a + wbi * C::WBUF;
+                // f16m8: fp8 operands of this piece's MX step; fetched in the middle of the piece (see chunk 1, n == 0)
+                v8i x8[SPLIT == 2 ? MF : 1];
+                long long x8q[SPLIT == 2 ? MF : 1][4];
                 lds_read128<0>(wr[0][0], wp);
-                if constexpr (SPLIT) lds_read128<1024>(wr[0][1], wp);
+                if constexpr (SPLIT == 1) lds_read128<1024>(wr[0][1], wp);
                 // next weight piece: the following piece of this slab, else the first piece of what comes next
                 if (p + 1 < npiece) {
-                    const int rem = nchunk - (ch0 + C::PCH);
+                    const int rem = wchunk - (ch0 + C::PCH);
                     stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
                 } else if (have_next) {
-                    const int nch = chunks_of(nc8n);
+                    const int nch = wchunks_of(nc8n);
                     stage_w(nwoff, nch < C::PCH ? nch : C::PCH, wbi ^ 1);
                 }
                 int hnow = 0;
@@ -357,14 +393,14 @@ conv3d_f16_mfma(ConvArgs a)
                             constexpr int n = decltype(nc)::value;
                             constexpr int cur = (par0 + n) & 1, nxt = cur ^ 1;
                             constexpr bool more_n = (n + 1 < NF), more_c = (cc + 1 < C::PCH);
-                            constexpr int wo = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::FRAG;
+                            constexpr int wo = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::MFRAG;
                             if constexpr ((more_n || more_c) && !(SN_ABL & 16)) {
                                 lds_read128<wo>(wr[nxt][0], wp);
-                                if constexpr (SPLIT) lds_read128<wo + 1024>(wr[nxt][1], wp);
+                                if constexpr (SPLIT == 1) lds_read128<wo + 1024>(wr[nxt][1], wp);
                             }
-                            lgkm_wait<((more_n || more_c) ? NPL : 0) + (n == 1 ? 1 + MF * NPL : 0)>();
+                            lgkm_wait<((more_n || more_c) ? NPLM : 0) + (n == 1 ? 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? 4 * MF + 1 : 0) : 0)>();
                             if constexpr (!(SN_ABL & 4)) {
-                                if constexpr (SPLIT) {
+                                if constexpr (SPLIT == 1) {
 #pragma unroll
                                     for (int m = 0; m < MF; ++m)
                                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][1], xc[0][m], acc[m][n], 0, 0, 0);
@@ -381,15 +417,60 @@ conv3d_f16_mfma(ConvArgs a)
                             if constexpr (n == 0) {
                                 lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
                                 issue_x(xn, ko1);
+                                if constexpr (SPLIT == 2 && cc == 0) {
+                                    // fp8 operand fetch for the MX step that closes this piece (tap offsets k4 were read one
+                                    // piece ahead); also fetch the next piece's tap offsets
+                                    static_for<0, MF>([&](auto mc) {
+                                        constexpr int m = decltype(mc)::value;
+                                        const unsigned ad = xaddr[m] + C::XPLANE + (kq >> 1) * 8;   // lanes 0-31: fp8(hi), 32-63: fp8(lo*2^12)
+                                        lds_read64<0>(x8q[m][0], ad + (unsigned)k4[0]);
+                                        lds_read64<0>(x8q[m][1], ad + (unsigned)k4[1]);
+                                        lds_read64<0>(x8q[m][2], ad + (unsigned)k4[2]);
+                                        lds_read64<0>(x8q[m][3], ad + (unsigned)k4[3]);
+                                    });
+                                    lds_read128i<0>(k4n, k4_a + (unsigned)(8 * (p + 1)) * 4);
+                                }
                             }
                         });
-                        lgkm_wait<(cc + 1 < C::PCH) ? NPL : 0>();   // X(c+1), koff(c+2) landed; W(c+1,0) may be in flight
+                        lgkm_wait<(cc + 1 < C::PCH) ? NPLM : 0>();   // X(c+1), koff(c+2) landed; W(c+1,0) may be in flight
 #pragma unroll
                         for (int m = 0; m < MF; ++m) {
                             xc[0][m] = xn[0][m];
-                            if constexpr (SPLIT) xc[1][m] = xn[1][m];
+                            if constexpr (SPLIT == 1) xc[1][m] = xn[1][m];
                         }
                         ko1 = ko2;
+                    }
+                    if constexpr (SPLIT == 2 && cc == 0) {
+                        // MX step (placed between the piece's two f16 chunks so the fp8 operands are short-lived): both correction
+                        // terms of this piece's 64 k in one fp8 MFMA per (cout, voxel) fragment pair;
+                        // scale_a = 2^-12 (E8M0 115): the packed lo parts were multiplied by 2^12
+                        constexpr int mxo = 2 * NF * 1024;
+    #pragma unroll
+                        for (int m = 0; m < MF; ++m) {
+                            x8[m][0] = (int)x8q[m][0]; x8[m][1] = (int)(x8q[m][0] >> 32); x8[m][2] = (int)x8q[m][1]; x8[m][3] = (int)(x8q[m][1] >> 32);
+                            x8[m][4] = (int)x8q[m][2]; x8[m][5] = (int)(x8q[m][2] >> 32); x8[m][6] = (int)x8q[m][3]; x8[m][7] = (int)(x8q[m][3] >> 32);
+                        }
+                        k4 = k4n;
+                        v4i w8[2][2];
+                        lds_read128i<mxo>(w8[0][0], wp);
+                        lds_read128i<mxo + 1024>(w8[0][1], wp);
+                        static_for<0, NF>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            constexpr int cur = n & 1, nxt = cur ^ 1;
+                            if constexpr (n + 1 < NF) {
+                                lds_read128i<mxo + (n + 1) * 2048>(w8[nxt][0], wp);
+                                lds_read128i<mxo + (n + 1) * 2048 + 1024>(w8[nxt][1], wp);
+                            }
+                            lgkm_wait<(n + 1 < NF) ? 2 : 0>();
+                            v8i wa;
+                            wa[0] = w8[cur][0][0]; wa[1] = w8[cur][0][1]; wa[2] = w8[cur][0][2]; wa[3] = w8[cur][0][3];
+                            wa[4] = w8[cur][1][0]; wa[5] = w8[cur][1][1]; wa[6] = w8[cur][1][2]; wa[7] = w8[cur][1][3];
+                            if constexpr (!(SN_ABL & 4)) {
+    #pragma unroll
+                                for (int m = 0; m < MF; ++m)
+                                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, x8[m], acc[m][n], 0, 0, 0, 115, 0, 127);
+                            }
+                        });
                     }
                 });
                 lgkm_wait<0>();
@@ -401,7 +482,7 @@ conv3d_f16_mfma(ConvArgs a)
             }
             xb ^= 1;
             c0 += c8n;
-            woff += (size_t)nchunk * NF * C::FRAG;
+            woff += (size_t)wchunk * NF * C::FRAG;
         }
 
         // ---- epilogue: folded BN affine + activation --------------------------------------------------------
@@ -418,20 +499,30 @@ conv3d_f16_mfma(ConvArgs a)
                         const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
                         const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
                         half4 h, l;
+                        float lo32[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float y = acc[m][n][r] * sc[r] + sh[r];
                             y = a.act == 0 ? fmaxf(y, 0.f) : sn_sigmoid(y);
-                            if constexpr (SPLIT) {
+                            if constexpr (SPLIT == 1) {
                                 _Float16 hh, ll;
                                 sn_split(y, hh, ll);
                                 h[r] = hh; l[r] = ll;
-                            } else h[r] = (_Float16)y;
+                            } else {
+                                h[r] = (_Float16)y;
+                                lo32[r] = (y - (float)h[r]) * 4096.f;
+                            }
                         }
                         const int ch = a.out_coff + nl;   // group-blocked layout: [b][ch/8][x][y][z][ch%8]
                         _Float16 *o = a.out + (size_t)b * D * D * D * a.out_cs + ((size_t)(ch >> 3) * D * D * D + vlin) * 8 + (ch & 7);
                         *reinterpret_cast<half4 *>(o) = h;
-                        if constexpr (SPLIT) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
+                        if constexpr (SPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
+                        if constexpr (SPLIT == 2) {
+                            // second plane, 16-byte slot per (voxel, group): [fp8(hi) c0..c7 | fp8(lo*2^12) c0..c7]
+                            char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.out_lo_off);
+                            *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                            *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                        }
                     }
                 }
             }

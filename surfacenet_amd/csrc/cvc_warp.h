@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "elementwise.h"
+
 namespace sn {
 
 struct CvcArgs {
@@ -26,7 +28,8 @@ struct CvcArgs {
     const int *img_h, *img_w;  // (V,)
     float *out_ncdhw;          // (n*n_vp, 6, s,s,s) or nullptr
     _Float16 *out_x0;          // (n*n_vp, s,s,s, 8) fp16 mean-subtracted, or nullptr
-    long long x0_lo_off;       // != 0: also write the lo plane (value - hi) at out_x0 + x0_lo_off (f16x3 mode)
+    long long x0_lo_off;       // second plane of x0 (element offset from out_x0), used when x0_mode != 0
+    int x0_mode;               // 0: fp16 only; 1: fp16 lo plane (f16x3); 2: [fp8(hi) | fp8(lo*2^12)] slot (f16m8)
     float mean[6];
     int sub_mean_ncdhw;        // 1: planar output is value - mean (preprocess), 0: raw 0..255
     int n_vp, s, V;
@@ -81,39 +84,33 @@ __global__ void __launch_bounds__(256) cvc_warp_kernel(CvcArgs a)
     }
     if (a.out_x0) {
         typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-        half8 h, l;
+        float y[8];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const float y = rgb[c] - a.mean[c];
-            h[c] = (_Float16)y;
-            l[c] = (_Float16)(y - (float)h[c]);
-        }
-        h[6] = h[7] = l[6] = l[7] = (_Float16)0.f;
+        for (int c = 0; c < 6; ++c) y[c] = rgb[c] - a.mean[c];
+        y[6] = y[7] = 0.f;
         _Float16 *o = a.out_x0 + ((size_t)sample * s3 + vox) * 8;
-        *reinterpret_cast<half8 *>(o) = h;
-        if (a.x0_lo_off) *reinterpret_cast<half8 *>(o + a.x0_lo_off) = l;
+        if (a.x0_mode == 1) sn_store8<1>(o, a.x0_lo_off, y);
+        else if (a.x0_mode == 2) sn_store8<2>(o, a.x0_lo_off, y);
+        else sn_store8<0>(o, 0, y);
     }
 }
 
 // NCDHW fp32 (the reference's network input, already mean-subtracted) -> channels-last fp16 x0.
-__global__ void __launch_bounds__(256) ncdhw_to_x0_kernel(const float *X, _Float16 *x0, int s3, int nsamples, long long x0_lo_off)
+__global__ void __launch_bounds__(256) ncdhw_to_x0_kernel(const float *X, _Float16 *x0, int s3, int nsamples, long long x0_lo_off, int x0_mode)
 {
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const int vox = blockIdx.x * 256 + threadIdx.x;
     const int sample = blockIdx.y;
     if (vox >= s3 || sample >= nsamples) return;
     const float *src = X + (size_t)sample * 6 * s3 + vox;
-    half8 h, l;
+    float y[8];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const float y = src[(size_t)c * s3];
-        h[c] = (_Float16)y;
-        l[c] = (_Float16)(y - (float)h[c]);
-    }
-    h[6] = h[7] = l[6] = l[7] = (_Float16)0.f;
+    for (int c = 0; c < 6; ++c) y[c] = src[(size_t)c * s3];
+    y[6] = y[7] = 0.f;
     _Float16 *o = x0 + ((size_t)sample * s3 + vox) * 8;
-    *reinterpret_cast<half8 *>(o) = h;
-    if (x0_lo_off) *reinterpret_cast<half8 *>(o + x0_lo_off) = l;
+    if (x0_mode == 1) sn_store8<1>(o, x0_lo_off, y);
+    else if (x0_mode == 2) sn_store8<2>(o, x0_lo_off, y);
+    else sn_store8<0>(o, 0, y);
 }
 
 }  // namespace sn

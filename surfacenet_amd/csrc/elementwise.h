@@ -13,6 +13,60 @@ namespace sn {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+// One 8-channel group of an activation tensor <-> 8 fp32 values, for the three storage modes of conv3d_mfma.h:
+//   SPLIT 0: fp16;  SPLIT 1: hi + lo fp16 planes;  SPLIT 2: fp16 hi plane + 16-byte slot [fp8(hi) x8 | fp8(lo*2^12) x8].
+template <int SPLIT>
+__device__ __forceinline__ void sn_load8(const _Float16 *p, long long lo_off, float (&v)[8])
+{
+    const h8 q = *reinterpret_cast<const h8 *>(p);
+    if constexpr (SPLIT == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)q[e];
+    } else if constexpr (SPLIT == 1) {
+        const h8 ql = *reinterpret_cast<const h8 *>(p + lo_off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)q[e] + (float)ql[e];
+    } else {
+        const uint4 s = *reinterpret_cast<const uint4 *>(p + lo_off);
+        const float sc = 1.0f / 4096.0f;
+        v[0] = (float)q[0] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 0) * sc; v[1] = (float)q[1] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 1) * sc;
+        v[2] = (float)q[2] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 2) * sc; v[3] = (float)q[3] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 3) * sc;
+        v[4] = (float)q[4] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 0) * sc; v[5] = (float)q[5] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 1) * sc;
+        v[6] = (float)q[6] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 2) * sc; v[7] = (float)q[7] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 3) * sc;
+    }
+}
+__device__ __forceinline__ int sn_fp8x4(float a, float b, float c, float d)
+{
+    auto cl = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
+}
+template <int SPLIT>
+__device__ __forceinline__ void sn_store8(_Float16 *p, long long lo_off, const float (&v)[8])
+{
+    h8 h;
+    float lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = (_Float16)v[e];
+        lo[e] = v[e] - (float)h[e];
+    }
+    *reinterpret_cast<h8 *>(p) = h;
+    if constexpr (SPLIT == 1) {
+        h8 l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = (_Float16)lo[e];
+        *reinterpret_cast<h8 *>(p + lo_off) = l;
+    } else if constexpr (SPLIT == 2) {
+        uint4 s;
+        s.x = (unsigned)sn_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        s.y = (unsigned)sn_fp8x4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+        s.z = (unsigned)sn_fp8x4(lo[0] * 4096.f, lo[1] * 4096.f, lo[2] * 4096.f, lo[3] * 4096.f);
+        s.w = (unsigned)sn_fp8x4(lo[4] * 4096.f, lo[5] * 4096.f, lo[6] * 4096.f, lo[7] * 4096.f);
+        *reinterpret_cast<uint4 *>(p + lo_off) = s;
+    }
+}
+
 // in [B][C/8][D][D][D][8] -> out [B][C/8][D/2][D/2][D/2][8]; one thread = one output voxel of one 8-channel group.
 // SPLIT: values are hi+lo pairs of fp16 planes (lo plane at +lo_off elements); the max is taken on hi+lo.
 template <int SPLIT>
@@ -30,31 +84,15 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const _Float16 *in, _Floa
     const long long b = t / c8n;
     // group-blocked layout [b][c8][x][y][z][8]
     const _Float16 *p = in + (((b * c8n + c8) * D + 2 * x) * D + 2 * y) * (long long)D * 8 + 2 * z * 8;
-    h8 m = *reinterpret_cast<const h8 *>(p), ml;
-    float mv[8];
-    if constexpr (SPLIT) {
-        ml = *reinterpret_cast<const h8 *>(p + in_lo_off);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mv[e] = (float)m[e] + (float)ml[e];
-    }
+    float m[8], q[8];
+    sn_load8<SPLIT>(p, in_lo_off, m);
 #pragma unroll
     for (int o = 1; o < 8; ++o) {
-        const _Float16 *pq = p + ((long long)((o >> 2) * D + ((o >> 1) & 1)) * D + (o & 1)) * 8;
-        const h8 q = *reinterpret_cast<const h8 *>(pq);
-        if constexpr (SPLIT) {
-            const h8 ql = *reinterpret_cast<const h8 *>(pq + in_lo_off);
+        sn_load8<SPLIT>(p + ((long long)((o >> 2) * D + ((o >> 1) & 1)) * D + (o & 1)) * 8, in_lo_off, q);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float qv = (float)q[e] + (float)ql[e];
-                if (qv > mv[e]) { mv[e] = qv; m[e] = q[e]; ml[e] = ql[e]; }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) m[e] = q[e] > m[e] ? q[e] : m[e];
-        }
+        for (int e = 0; e < 8; ++e) m[e] = q[e] > m[e] ? q[e] : m[e];
     }
-    *reinterpret_cast<h8 *>(out + idx * 8) = m;
-    if constexpr (SPLIT) *reinterpret_cast<h8 *>(out + out_lo_off + idx * 8) = ml;
+    sn_store8<SPLIT>(out + idx * 8, out_lo_off, m);
 }
 
 // Per-axis operator of the "bilinear" upsampler: output index o = F*m + ph reads
@@ -109,26 +147,14 @@ __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, 
         const float w = (dx ? bx : ax) * (dy ? by : ay) * (dz ? bz : az);
         if (w != 0.f) {
             const _Float16 *pq = in + (((((b * 2 + c8) * Di + mx + dx) * Di + my + dy) * Di + mz + dz) * 8LL);
-            const h8 q = *reinterpret_cast<const h8 *>(pq);
-            if constexpr (SPLIT) {
-                const h8 ql = *reinterpret_cast<const h8 *>(pq + in_lo);
+            float q[8];
+            sn_load8<SPLIT>(pq, in_lo, q);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w * ((float)q[e] + (float)ql[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w * (float)q[e];
-            }
+            for (int e = 0; e < 8; ++e) acc[e] += w * q[e];
         }
     }
-    h8 r, rl;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        r[e] = (_Float16)acc[e];
-        if constexpr (SPLIT) rl[e] = (_Float16)(acc[e] - (float)r[e]);
-    }
     _Float16 *o = cat + ((((b * (cat_cs >> 3) + 2 + g) * Do + x) * Do + y) * Do + z) * 8LL;
-    *reinterpret_cast<h8 *>(o) = r;
-    if constexpr (SPLIT) *reinterpret_cast<h8 *>(o + out_lo_off) = rl;
+    sn_store8<SPLIT>(o, out_lo_off, acc);
 }
 
 // unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.

@@ -188,8 +188,34 @@ static int prof_drain(sn_ctx *c)
 // ------------------------------------------------------------------------------------------------
 // weight preparation
 // ------------------------------------------------------------------------------------------------
+// OCP fp8 e4m3fn encoder (round-to-nearest-even, saturating at +-448), the format v_mfma_scale_f32_16x16x128_f8f6f4
+// consumes with cbsz/blgp = 0 on gfx950.
+static unsigned char fp8_e4m3(float v)
+{
+    if (v != v) return 0x7f;
+    const unsigned char sgn = std::signbit(v) ? 0x80 : 0;
+    float a = std::fabs(v);
+    if (a >= 448.f) return sgn | 0x7e;                       // max finite 1.75 * 2^8
+    if (a < std::ldexp(1.0f, -10)) return sgn;               // below half of the smallest subnormal (2^-9)
+    int e;
+    std::frexp(a, &e);                                       // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                                           // a = (1 + f) * 2^E
+    if (E < -6) E = -6;                                      // subnormal range: fixed exponent 2^-6, mantissa step 2^-9
+    const float q = std::nearbyint(std::ldexp(a, 3 - E));    // mantissa in units of 2^(E-3): 8..15 normal, 0..7 subnormal
+    int mant = (int)q, be = E + 7;
+    if (E == -6 && mant < 8) be = 0;                         // subnormal encoding
+    else { if (mant == 16) { mant = 8; be += 1; } mant -= 8; }
+    if (be > 15 || (be == 15 && mant > 6)) return sgn | 0x7e;
+    return sgn | (unsigned char)(be << 3) | (unsigned char)mant;
+}
+
 // W is given as (cout, cin, k,k,k) row-major fp32 (dilated layers are transposed by the caller).
-// Packed layout: [nsplit][slab][chunk][nf]{ hi fragment (64 lanes x 8 halfs) [, lo fragment] }.
+// Packed layouts (one stream per cout split, slabs back to back):
+//   split 0 (f16)  : [slab][chunk][nf]{ hi fragment: 64 lanes x 8 halfs }
+//   split 1 (f16x3): [slab][chunk][nf]{ hi fragment, lo fragment }
+//   split 2 (f16m8): [slab][piece of 8 groups]{ chunk 2p: nf hi fragments | chunk 2p+1: nf hi fragments |
+//                     nf MX fragments (2 KiB: k bytes 0-15 of all 64 lanes, then 16-31); lane (row = l&15, q = l>>4): q<2 -> fp8(w_lo * 2^12) of
+//                     groups 8p+4q..+3, q>=2 -> fp8(w_hi) of groups 8p+4(q-2)..+3 }   (every piece is full-size, zero padded)
 static int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const float *gamma, const float *mean,
                      const float *inv_std, int nf, int nsplit, int cs8max, int split)
 {
@@ -197,38 +223,83 @@ static int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta
     L.cin_p = round_up(L.cin, 8);
     const int ntap = L.ks * L.ks * L.ks;
     const int c8_total = L.cin_p / 8;
-    const int npl = split ? 2 : 1;
+    const int npl = split == 1 ? 2 : 1;
     L.slab_c8.clear();
     for (int left = c8_total; left > 0; left -= cs8max) L.slab_c8.push_back((unsigned char)std::min(left, cs8max));
     if ((int)L.slab_c8.size() > kMaxSlab) return fail(SN_ERR_ARG, "%s: too many channel slabs", L.name.c_str());
-    long long chunks = 0;
-    for (unsigned char c8n : L.slab_c8) chunks += (ntap * c8n + 3) / 4;
-    L.wsplit_stride = chunks * nf * 512 * npl;
-    std::vector<_Float16> h((size_t)L.wsplit_stride * nsplit, (_Float16)0.f);
-    for (int ns = 0; ns < nsplit; ++ns) {
-        _Float16 *dst = h.data() + (size_t)ns * L.wsplit_stride;
-        int c8_0 = 0;
-        for (unsigned char c8n : L.slab_c8) {
-            const int G = ntap * c8n, nchunk = (G + 3) / 4;
-            for (int ch = 0; ch < nchunk; ++ch)
-                for (int f = 0; f < nf; ++f)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int o = (ns * nf + f) * 16 + (lane & 15);
-                        const int g = 4 * ch + (lane >> 4);
-                        _Float16 *d8 = dst + (((size_t)ch * nf + f) * npl * 64 + lane) * 8;
-                        if (g >= G || o >= L.cout) continue;
-                        const int tap = g / c8n, c8 = g % c8n;
-                        for (int j = 0; j < 8; ++j) {
-                            const int ci = (c8_0 + c8) * 8 + j;
-                            if (ci >= L.cin) continue;
-                            const float w = W[((size_t)o * L.cin + ci) * ntap + tap];
-                            const _Float16 hi = (_Float16)w;
-                            d8[j] = hi;
-                            if (split) d8[512 + j] = (_Float16)(w - (float)hi);
+    auto wat = [&](int o, int c8abs, int j, int tap) -> float {
+        const int ci = c8abs * 8 + j;
+        return (o < L.cout && ci < L.cin) ? W[((size_t)o * L.cin + ci) * ntap + tap] : 0.f;
+    };
+    std::vector<_Float16> h;
+    if (split != 2) {
+        long long chunks = 0;
+        for (unsigned char c8n : L.slab_c8) chunks += (ntap * c8n + 3) / 4;
+        L.wsplit_stride = chunks * nf * 512 * npl;
+        h.assign((size_t)L.wsplit_stride * nsplit, (_Float16)0.f);
+        for (int ns = 0; ns < nsplit; ++ns) {
+            _Float16 *dst = h.data() + (size_t)ns * L.wsplit_stride;
+            int c8_0 = 0;
+            for (unsigned char c8n : L.slab_c8) {
+                const int G = ntap * c8n, nchunk = (G + 3) / 4;
+                for (int ch = 0; ch < nchunk; ++ch)
+                    for (int f = 0; f < nf; ++f)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int o = (ns * nf + f) * 16 + (lane & 15);
+                            const int g = 4 * ch + (lane >> 4);
+                            _Float16 *d8 = dst + (((size_t)ch * nf + f) * npl * 64 + lane) * 8;
+                            if (g >= G) continue;
+                            for (int j = 0; j < 8; ++j) {
+                                const float w = wat(o, c8_0 + g % c8n, j, g / c8n);
+                                const _Float16 hi = (_Float16)w;
+                                d8[j] = hi;
+                                if (split == 1) d8[512 + j] = (_Float16)(w - (float)hi);
+                            }
                         }
-                    }
-            dst += (size_t)nchunk * nf * 512 * npl;
-            c8_0 += c8n;
+                dst += (size_t)nchunk * nf * 512 * npl;
+                c8_0 += c8n;
+            }
+        }
+    } else {
+        long long pieces = 0;
+        for (unsigned char c8n : L.slab_c8) pieces += (ntap * c8n + 7) / 8;
+        const size_t piece_halfs = (size_t)nf * 2048;          // 2 chunks x nf x 1 KiB + nf x 2 KiB = 4*nf KiB
+        L.wsplit_stride = pieces * piece_halfs;
+        h.assign((size_t)L.wsplit_stride * nsplit, (_Float16)0.f);
+        for (int ns = 0; ns < nsplit; ++ns) {
+            _Float16 *dst = h.data() + (size_t)ns * L.wsplit_stride;
+            int c8_0 = 0;
+            for (unsigned char c8n : L.slab_c8) {
+                const int G = ntap * c8n, npiece = (G + 7) / 8;
+                for (int p = 0; p < npiece; ++p, dst += piece_halfs) {
+                    for (int cc = 0; cc < 2; ++cc)
+                        for (int f = 0; f < nf; ++f)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int o = (ns * nf + f) * 16 + (lane & 15);
+                                const int g = 8 * p + 4 * cc + (lane >> 4);
+                                if (g >= G) continue;
+                                _Float16 *d8 = dst + (((size_t)cc * nf + f) * 64 + lane) * 8;
+                                for (int j = 0; j < 8; ++j) d8[j] = (_Float16)wat(o, c8_0 + g % c8n, j, g / c8n);
+                            }
+                    unsigned char *mx = reinterpret_cast<unsigned char *>(dst + (size_t)2 * nf * 512);
+                    for (int f = 0; f < nf; ++f)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int o = (ns * nf + f) * 16 + (lane & 15), q = lane >> 4;
+                            unsigned char *frag = mx + (size_t)f * 2048;   // two lane-linear 1 KiB halves: k bytes 0-15 | 16-31
+                            for (int i = 0; i < 4; ++i) {
+                                const int g = 8 * p + 4 * (q & 1) + i;
+                                if (g >= G) continue;
+                                for (int j = 0; j < 8; ++j) {
+                                    const float w = wat(o, c8_0 + g % c8n, j, g / c8n);
+                                    const float hi = (float)(_Float16)w;
+                                    const int kb = i * 8 + j;
+                                    frag[(kb >> 4) * 1024 + lane * 16 + (kb & 15)] = q < 2 ? fp8_e4m3((w - hi) * 4096.f) : fp8_e4m3(hi);
+                                }
+                            }
+                        }
+                }
+                c8_0 += c8n;
+            }
         }
     }
     std::vector<float> sc((size_t)nsplit * nf * 16 + 16, 0.f), sh((size_t)nsplit * nf * 16 + 16, 0.f);
@@ -260,12 +331,11 @@ struct TileChoice { int nf, nsplit, cs8max; };
 // Must agree with the kernel instantiations in run_net_t<SPLIT> (launch_conv verifies it).
 static TileChoice tile_for(const LayerSpec &sp, int split)
 {
-    (void)split;
     if (sp.kind == K_CONV1 || sp.kind == K_DIL1) return {1, 1, 5};
     if (sp.kind == K_DIL3) return {5, 4, 1};        // conv4: dilation-2 halo is big -> 8-channel slabs; 4 x 80 output channels
     if (sp.cout == 32) return {2, 1, 1};
-    if (sp.cout == 80) return {5, 1, 2};
-    if (sp.cout == 160) return {5, 2, 2};
+    if (sp.cout == 80) return {5, 1, split == 2 ? 1 : 2};
+    if (sp.cout == 160) return {5, 2, split == 2 ? 1 : 2};
     return {7, 1, 1};  // cout 100
 }
 
@@ -342,10 +412,10 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
               ma = A(c->ma, v1, 104), none = Act{nullptr, 0};
     int rc;
 #define RUN(x) do { if ((rc = (x)) != SN_OK) return rc; } while (0)
-#define CONV1 3, 1, 4, 2, EPI_STORE, SP, 1, 7, 8, 0
+#define CONV1 3, 1, 4, 2, EPI_STORE, SP, 1, (SP == 2 ? 2 : 7), 8, 0
 #define SIDE  1, 1, 4, 1, EPI_STORE, SP, 5, 2, 4, 0
-#define CONV2 3, 1, 4, 5, EPI_STORE, SP, 2, 1, 8, 0
-#define CONV3 3, 1, 4, 5, EPI_STORE, SP, 2, 1, 8, 0
+#define CONV2 3, 1, 4, 5, EPI_STORE, SP, (SP == 2 ? 1 : 2), (SP == 2 ? 2 : 1), 8, 0
+#define CONV3 3, 1, 4, 5, EPI_STORE, SP, (SP == 2 ? 1 : 2), (SP == 2 ? 2 : 1), 8, 0
 #define CONV4 3, 2, 4, 5, EPI_STORE, SP, 1, 2, 8, 0
 #define MERGA 3, 1, 4, 7, EPI_STORE, SP, 1, 2, 8, 0
 #define MERGB 3, 1, 4, 7, EPI_FINAL, SP, 1, 2, 8, 0
@@ -375,7 +445,10 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     return SN_OK;
 }
 
-static int run_net(sn_ctx *c, int S, float *unf) { return c->split ? run_net_t<1>(c, S, unf) : run_net_t<0>(c, S, unf); }
+static int run_net(sn_ctx *c, int S, float *unf)
+{
+    return c->split == 2 ? run_net_t<2>(c, S, unf) : (c->split == 1 ? run_net_t<1>(c, S, unf) : run_net_t<0>(c, S, unf));
+}
 
 static int launch_fuse(sn_ctx *c, const float *unf, const float *w_dev, float *fused, int n, int n_vp)
 {
@@ -399,6 +472,7 @@ static int launch_cvc(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, cons
     a.img_base = c->img_base; a.img_off = c->img_off; a.img_h = c->img_h; a.img_w = c->img_w;
     a.out_ncdhw = out_ncdhw; a.out_x0 = out_x0;
     a.x0_lo_off = (out_x0 && c->split) ? (long long)c->max_samples * c->s * c->s * c->s * 8 : 0;
+    a.x0_mode = c->split;
     static const float kVggMean[6] = {123.68f, 116.779f, 103.939f, 123.68f, 116.779f, 103.939f};  // params.py:129
     for (int i = 0; i < 6; ++i) a.mean[i] = mean6 ? mean6[i] : kVggMean[i];
     a.sub_mean_ncdhw = sub_mean ? 1 : 0;
@@ -490,7 +564,7 @@ void sn_destroy(sn_ctx *c)
 int sn_set_precision(sn_ctx *c, int mode)
 {
     if (!c) return fail(SN_ERR_ARG, "null context");
-    if (mode != SN_PRECISION_F16 && mode != SN_PRECISION_F16X3) return fail(SN_ERR_ARG, "unknown precision mode %d", mode);
+    if (mode != SN_PRECISION_F16 && mode != SN_PRECISION_F16X3 && mode != SN_PRECISION_F16M8) return fail(SN_ERR_ARG, "unknown precision mode %d", mode);
     if (c->have_weights && mode != c->split) c->have_weights = false;   // weights must be re-packed for the new mode
     c->split = mode;
     return SN_OK;
@@ -676,7 +750,7 @@ int sn_forward_dev(sn_ctx *c, int n, int n_vp, const float *X_dev, const float *
     {
         ProfScope ps(c, "ncdhw_to_x0", 0, (double)S * s3 * (24.0 + 16.0));
         hipLaunchKernelGGL(ncdhw_to_x0_kernel, dim3((unsigned)((s3 + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, X_dev, c->x0, s3, S,
-                           c->split ? (long long)c->max_samples * s3 * 8 : 0LL);
+                           c->split ? (long long)c->max_samples * s3 * 8 : 0LL, c->split);
         HIPCHK(hipGetLastError());
     }
     float *unf = unfused_dev ? unfused_dev : c->unf_ws;

@@ -56,6 +56,9 @@ def test_cvc_bad_view_index(sn):
 #   emulates fp16 operand storage < 5e-3 (same noise class as the storage rounding itself, because a different
 #   summation order flips half-ulp fp16 roundings of stored activations)
 TOL_X3, TOL_F16_EMU, TOL_F16 = 1e-4, 5e-3, 1e-2
+#   f16m8 (f16 main term + MX-fp8 correction terms): vs fp64 < 5e-4 (observed ~1e-4; north-star bar 1e-3); vs the oracle
+#   that emulates its storage/operand formats < 2e-4
+TOL_M8, TOL_M8_EMU = 5e-4, 2e-4
 
 
 def _net_case(s, n, n_vp, seed):
@@ -66,7 +69,7 @@ def _net_case(s, n, n_vp, seed):
     return values, X, w
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16m8", "f16"])
 @pytest.mark.parametrize("s,n,n_vp", [(8, 3, 1), (16, 2, 2), (32, 1, 3)])
 def test_forward_vs_oracle(sn, s, n, n_vp, precision):
     from oracle import net_oracle
@@ -81,6 +84,11 @@ def test_forward_vs_oracle(sn, s, n, n_vp, precision):
     print("%s s=%d: L_inf vs fp64 oracle: unfused %.3e fused %.3e" % (precision, s, e_ref, e_fused))
     if precision == "f16x3":
         assert e_ref < TOL_X3 and e_fused < TOL_X3
+    elif precision == "f16m8":
+        fm, um = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp, quant="f16m8")
+        e_emu = np.abs(unfused - um).max()
+        print("   vs f16m8-emulating oracle %.3e (emulation itself vs fp64: %.3e)" % (e_emu, np.abs(um - u64).max()))
+        assert e_ref < TOL_M8 and e_fused < TOL_M8 and e_emu < TOL_M8_EMU
     else:
         f16, u16 = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp, quant="fp16")
         e_emu = np.abs(unfused - u16).max()
@@ -90,7 +98,7 @@ def test_forward_vs_oracle(sn, s, n, n_vp, precision):
         assert np.array_equal(fused, unfused)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16m8", "f16"])
 def test_cvc_forward_fused_path(sn, precision):
     from oracle import cvc_oracle, net_oracle
     import synth
@@ -107,7 +115,7 @@ def test_cvc_forward_fused_path(sn, precision):
     assert np.array_equal(cvc, ref_cvc)
     assert np.array_equal(fused, f2) and np.array_equal(unfused, u2)      # fused entry == 3-call protocol
     f64, u64 = net_oracle.forward_torch(ref_cvc, values, w=sc["w"], n_vp=n_vp)
-    tol = TOL_X3 if precision == "f16x3" else TOL_F16
+    tol = {"f16x3": TOL_X3, "f16m8": TOL_M8, "f16": TOL_F16}[precision]
     assert np.abs(unfused - u64).max() < tol and np.abs(fused - f64).max() < tol
 
 
