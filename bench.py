@@ -112,6 +112,8 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if local_rank >= torch.cuda.device_count():      # launcher restricted the visible devices to one per rank
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -440,7 +440,7 @@ conv3d_f16_mfma(ConvArgs a)
                         }
                         ko1 = ko2;
                     }
-                    if constexpr (SPLIT == 2 && cc == 0) {
+                    if constexpr (SPLIT == 2 && cc == 0 && !(SN_ABL & 256)) {
                         // MX step (placed between the piece's two f16 chunks so the fp8 operands are short-lived): both correction
                         // terms of this piece's 64 k in one fp8 MFMA per (cout, voxel) fragment pair;
                         // scale_a = 2^-12 (E8M0 115): the packed lo parts were multiplied by 2^12
@@ -465,7 +465,7 @@ conv3d_f16_mfma(ConvArgs a)
                             v8i wa;
                             wa[0] = w8[cur][0][0]; wa[1] = w8[cur][0][1]; wa[2] = w8[cur][0][2]; wa[3] = w8[cur][0][3];
                             wa[4] = w8[cur][1][0]; wa[5] = w8[cur][1][1]; wa[6] = w8[cur][1][2]; wa[7] = w8[cur][1][3];
-                            if constexpr (!(SN_ABL & 4)) {
+                            if constexpr (!(SN_ABL & (4 | 128))) {
     #pragma unroll
                                 for (int m = 0; m < MF; ++m)
                                     acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, x8[m], acc[m][n], 0, 0, 0, 115, 0, 127);

@@ -185,3 +185,15 @@ def test_relative_weight_mlp_vs_oracle(sn):
         ctx.load_param_values(values[:98])                       # network-only weight list: the MLP is unavailable
         with pytest.raises(sn.SurfaceNetHipError):
             ctx.relative_weights(f, 5)
+
+
+@pytest.mark.parametrize("s", [12, 20])
+def test_forward_ragged_cube_sizes(sn, s):
+    """Cube sizes that are not multiples of the 8x8x8 tile (partial tiles, odd pooled extents 6/3 and 10/5)."""
+    from oracle import net_oracle
+    values, X, w = _net_case(s, 2, 2, seed=3 + s)
+    with sn.Context(cube_D=s, max_samples=4) as ctx:
+        ctx.load_param_values(values)
+        fused, unfused = ctx.forward(X, w, n_vp=2)
+    f64, u64 = net_oracle.forward_torch(X, values, w=w, n_vp=2)
+    assert np.abs(unfused - u64).max() < TOL_X3 and np.abs(fused - f64).max() < TOL_X3
