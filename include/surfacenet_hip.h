@@ -121,6 +121,14 @@ int sn_cvc_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, cons
 int sn_forward_dev(sn_ctx *ctx, int n, int n_vp, const float *X_dev, const float *w_dev, float *fused_dev,
                    float *unfused_dev);
 
+/* ---- multi-GPU (one process per GPU): the path's only exchange is an all-gather of the per-cube fused probabilities
+ * (the reference is single-GPU, no counterpart). RCCL over xGMI; librccl is dlopen'ed on first use.
+ * Rank 0 calls sn_comm_unique_id and ships the 128 bytes to the other ranks by any means; every rank then calls
+ * sn_comm_init (collective). sn_allgather_f32_dev is asynchronous on the context's stream. */
+int sn_comm_unique_id(char *id128);
+int sn_comm_init(sn_ctx *ctx, int world, int rank, const char *id128);
+int sn_allgather_f32_dev(sn_ctx *ctx, const float *local_dev, size_t n_local, float *global_dev);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream. While enabled every kernel launch is
  * bracketed by events; sn_profile_get drains them. idx enumerates kernel tags (layer names);

@@ -18,6 +18,7 @@ ABI_SYMBOLS = [
     "sn_cvc", "sn_forward", "sn_cvc_forward", "sn_relative_weights", "sn_color_fuse", "sn_color_fuse_dev",
     "sn_dev_alloc", "sn_dev_free", "sn_memcpy_h2d", "sn_memcpy_d2h",
     "sn_cvc_forward_dev", "sn_cvc_dev", "sn_forward_dev",
+    "sn_comm_unique_id", "sn_comm_init", "sn_allgather_f32_dev",
     "sn_profile_enable", "sn_profile_count", "sn_profile_get", "sn_profile_reset",
 ]
 
@@ -72,6 +73,9 @@ def load():
         "sn_cvc_forward_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 8),
         "sn_cvc_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5),
         "sn_forward_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4),
+        "sn_comm_unique_id": (c_int, [ctypes.c_char_p]),
+        "sn_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p]),
+        "sn_allgather_f32_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
         "sn_profile_enable": (c_int, [c_void_p, c_int]),
         "sn_profile_count": (c_int, [c_void_p]),
         "sn_profile_get": (c_int, [c_void_p, c_int, ctypes.c_char_p, c_int, P(ctypes.c_double), P(ctypes.c_int64),

@@ -176,6 +176,19 @@ class Context(object):
         _lib.check(self._lib.sn_cvc_forward_dev(self._h, n, n_vp, pairs_dev, xyz_dev, resol_dev, _lib.ptr(m), w_dev, fused_dev,
                                                 unfused_dev, cvc_out_dev))
 
+    # ---- multi-GPU exchange (RCCL, native; torch.distributed is not required) ---------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().sn_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, world, rank, unique_id):
+        _lib.check(self._lib.sn_comm_init(self._h, int(world), int(rank), ctypes.c_char_p(bytes(unique_id))))
+
+    def allgather_f32_dev(self, local_dev, n_local, global_dev):
+        _lib.check(self._lib.sn_allgather_f32_dev(self._h, local_dev, int(n_local), global_dev))
+
     # ---- measurement --------------------------------------------------------------------------------
     def profile_enable(self, on=True):
         _lib.check(self._lib.sn_profile_enable(self._h, 1 if on else 0))

@@ -83,7 +83,6 @@ __global__ void __launch_bounds__(256) cvc_warp_kernel(CvcArgs a)
         for (int c = 0; c < 6; ++c) o[(size_t)c * s3] = a.sub_mean_ncdhw ? rgb[c] - a.mean[c] : rgb[c];
     }
     if (a.out_x0) {
-        typedef _Float16 half8 __attribute__((ext_vector_type(8)));
         float y[8];
 #pragma unroll
         for (int c = 0; c < 6; ++c) y[c] = rgb[c] - a.mean[c];
@@ -98,7 +97,6 @@ __global__ void __launch_bounds__(256) cvc_warp_kernel(CvcArgs a)
 // NCDHW fp32 (the reference's network input, already mean-subtracted) -> channels-last fp16 x0.
 __global__ void __launch_bounds__(256) ncdhw_to_x0_kernel(const float *X, _Float16 *x0, int s3, int nsamples, long long x0_lo_off, int x0_mode)
 {
-    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const int vox = blockIdx.x * 256 + threadIdx.x;
     const int sample = blockIdx.y;
     if (vox >= s3 || sample >= nsamples) return;

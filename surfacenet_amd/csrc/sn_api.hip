@@ -2,6 +2,7 @@
 // MFMA-fragment packing, activation workspace, the layer schedule of the SurfaceNet graph
 // (nets/SurfaceNet.py:18-76), and HIP-event profiling. Build: surfacenet_amd/csrc/Makefile.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -93,6 +94,7 @@ struct sn_ctx {
     std::map<std::string, PackedConv> conv;
     float *w3 = nullptr; float scale3 = 0, shift3 = 0;
     void *zero_page = nullptr; int num_cus = 256;
+    void *rccl_comm = nullptr; int comm_world = 0, comm_rank = 0;   // RCCL communicator (lazy dlopen of librccl)
     float *relw_W1 = nullptr, *relw_scale = nullptr, *relw_shift = nullptr, *relw_w2 = nullptr; float relw_b2 = 0;
     // activation workspace (channels-last fp16)
     _Float16 *x0 = nullptr, *a1 = nullptr, *b1 = nullptr, *cat = nullptr, *p1 = nullptr, *a2 = nullptr, *b2 = nullptr,
@@ -487,6 +489,8 @@ static int launch_cvc(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, cons
     return SN_OK;
 }
 
+static void comm_destroy_impl(sn_ctx *c);   // RCCL communicator teardown (defined with the RCCL glue below)
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -554,6 +558,7 @@ void sn_destroy(sn_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_destroy_impl(c);
     for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (void *p : c->owned) (void)hipFree(p);
@@ -944,6 +949,87 @@ int sn_color_fuse(sn_ctx *c, int n, int n_vp, const float *cvc, const float *mea
     (void)hipFree(d_c); (void)hipFree(d_u); (void)hipFree(d_wt); (void)hipFree(d_r);
     if (e != hipSuccess) return fail(SN_ERR_HIP, "sn_color_fuse: %s", hipGetErrorString(e));
     return rc;
+}
+
+// ---- multi-GPU exchange: RCCL all-gather over xGMI (the one collective of the path) ---------------------
+// librccl is dlopen'ed on first use, so single-GPU users never load it and a host that already carries an RCCL
+// (e.g. torch) keeps its own copy. ncclUniqueId = 128 opaque bytes; ncclFloat32 = 7.
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, const char (*)[128], int) = nullptr;   // real ABI passes the 128-byte struct by value
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+struct UniqueId { char b[128]; };
+Rccl g_rccl;
+int rccl_load()
+{
+    if (g_rccl.h) return SN_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(SN_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void **, int, const char (*)[128], int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+        return fail(SN_ERR_COMM, "librccl lacks an expected symbol");
+    g_rccl.h = h;
+    return SN_OK;
+}
+const char *rccl_err(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "rccl error"; }
+}  // namespace
+
+}  // extern "C" (reopened below)
+static void comm_destroy_impl(sn_ctx *c)
+{
+    if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
+    c->rccl_comm = nullptr;
+}
+extern "C" {
+
+int sn_comm_unique_id(char *id128)
+{
+    if (!id128) return fail(SN_ERR_ARG, "null argument");
+    int rc = rccl_load();
+    if (rc != SN_OK) return rc;
+    const int e = g_rccl.GetUniqueId(id128);
+    if (e != 0) return fail(SN_ERR_COMM, "ncclGetUniqueId: %s", rccl_err(e));
+    return SN_OK;
+}
+
+int sn_comm_init(sn_ctx *c, int world, int rank, const char *id128)
+{
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SN_ERR_ARG, "bad argument");
+    int rc = rccl_load();
+    if (rc != SN_OK) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->rccl_comm) { g_rccl.CommDestroy(c->rccl_comm); c->rccl_comm = nullptr; }
+    UniqueId uid;
+    memcpy(uid.b, id128, 128);
+    typedef int (*init_fn)(void **, int, UniqueId, int);                   // ncclUniqueId is passed BY VALUE
+    const int e = ((init_fn)g_rccl.CommInitRank)(&c->rccl_comm, world, uid, rank);
+    if (e != 0) { c->rccl_comm = nullptr; return fail(SN_ERR_COMM, "ncclCommInitRank: %s", rccl_err(e)); }
+    c->comm_world = world; c->comm_rank = rank;
+    return SN_OK;
+}
+
+// Every rank contributes n_local floats (device); global_dev receives world*n_local floats in rank order. Asynchronous
+// on the context's stream (use sn_synchronize).
+int sn_allgather_f32_dev(sn_ctx *c, const float *local_dev, size_t n_local, float *global_dev)
+{
+    if (!c || !local_dev || !global_dev) return fail(SN_ERR_ARG, "null argument");
+    if (!c->rccl_comm) return fail(SN_ERR_STATE, "sn_comm_init has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    ProfScope ps(c, "rccl_allgather", 0, (double)n_local * 4.0 * c->comm_world);
+    const int e = g_rccl.AllGather(local_dev, global_dev, n_local, /*ncclFloat32*/ 7, c->rccl_comm, c->stream);
+    if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather: %s", rccl_err(e));
+    return SN_OK;
 }
 
 // ---- raw device memory helpers (for hosts without a GPU array library) -------------------------------

@@ -197,3 +197,16 @@ def test_forward_ragged_cube_sizes(sn, s):
         fused, unfused = ctx.forward(X, w, n_vp=2)
     f64, u64 = net_oracle.forward_torch(X, values, w=w, n_vp=2)
     assert np.abs(unfused - u64).max() < TOL_X3 and np.abs(fused - f64).max() < TOL_X3
+
+
+def test_native_rccl_allgather_single_rank(sn):
+    """C-ABI RCCL path (librccl dlopen'ed lazily) with a 1-rank communicator: all-gather == copy."""
+    with sn.Context(cube_D=8, max_samples=2) as ctx:
+        ctx.comm_init(1, 0, sn.Context.comm_unique_id())
+        a = np.arange(5000, dtype=np.float32) * 0.5
+        d_a, d_b = ctx.upload(a), ctx.dev_alloc(a.nbytes)
+        ctx.allgather_f32_dev(d_a, a.size, d_b)
+        ctx.synchronize()
+        b = np.empty_like(a)
+        ctx.d2h(b, d_b)
+        assert np.array_equal(a, b)
