@@ -53,6 +53,12 @@
 #ifndef SN_HALO_AUX
 #define SN_HALO_AUX 0
 #endif
+#ifndef SN_XCD_REMAP
+#define SN_XCD_REMAP 1   // +0.7 % end to end (A/B, profiles/r1): neighbouring tiles share halos in one XCD's L2
+#endif
+#ifndef SN_SETPRIO
+#define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
+#endif
 
 namespace sn {
 
@@ -196,7 +202,13 @@ conv3d_f16_mfma(ConvArgs a)
     const int v = lane & 15, kq = lane >> 4;
     const int D = a.D;
     const int tstride = gridDim.x;
+#if SN_XCD_REMAP
+    // XCD-aware walk (speed only): workgroup i is observed to run on XCD i % 8; within each round of gridDim.x tiles XCD x
+    // takes the contiguous run [x*G/8, (x+1)*G/8) so that neighbouring tiles (shared halos) meet in one L2.
+    int tile = ((gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+#else
     int tile = blockIdx.x;
+#endif
     if (tile >= a.total_tiles) return;
 
     const char *const wsrc0 = reinterpret_cast<const char *>(a.wpack + (size_t)blockIdx.y * a.wsplit_stride);
@@ -400,6 +412,7 @@ conv3d_f16_mfma(ConvArgs a)
                             }
                             lgkm_wait<((more_n || more_c) ? NPLM : 0) + (n == 1 ? 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? 4 * MF + 1 : 0) : 0)>();
                             if constexpr (!(SN_ABL & 4)) {
+                                if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(1);
                                 if constexpr (SPLIT == 1) {
 #pragma unroll
                                     for (int m = 0; m < MF; ++m)
@@ -411,6 +424,7 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                                 for (int m = 0; m < MF; ++m)
                                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[0][m], acc[m][n], 0, 0, 0);
+                                if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(0);
                             } else {
                                 asm volatile("" ::"v"(wr[cur][0]), "v"(xc[0][0]));
                             }
