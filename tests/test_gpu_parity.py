@@ -210,3 +210,46 @@ def test_native_rccl_allgather_single_rank(sn):
         b = np.empty_like(a)
         ctx.d2h(b, d_b)
         assert np.array_equal(a, b)
+
+
+def test_error_paths_and_state_machine(sn):
+    """Call-order and argument errors surface as SurfaceNetHipError with the library's message (never a silent fallback)."""
+    from surfacenet_amd import weights
+    c = CASES["dtu_s8_vp1"]
+    with sn.Context(cube_D=8, max_samples=4) as ctx:
+        X = np.zeros((2, 6, 8, 8, 8), np.float32)
+        with pytest.raises(sn.SurfaceNetHipError, match="sn_load_weights"):
+            ctx.forward(X, None, n_vp=1)                                   # weights not loaded
+        with pytest.raises(sn.SurfaceNetHipError, match="sn_set_images"):
+            ctx.cvc(c["pairs"], c["xyz"], c["resol"])                      # scene not bound
+        ctx.load_param_values(weights.synthetic_param_values(0))
+        with pytest.raises(TypeError):
+            ctx.forward(X.astype(np.float64), None, n_vp=1)                # Theano-style dtype check
+        with pytest.raises(TypeError):
+            ctx.forward(X, np.ones((1, 2), np.float64), n_vp=2)            # w must be float32 (T.matrix is floatX)
+        with pytest.raises(ValueError):
+            ctx.forward(np.zeros((3, 6, 8, 8, 8), np.float32), np.ones((1, 2), np.float32), n_vp=2)
+        ctx.set_cameras(c["P"])
+        with pytest.raises(sn.SurfaceNetHipError, match="image count"):
+            ctx.set_images(golden_util.case_images(c)[:2]); ctx.cvc(c["pairs"][:1, :, :] * 0, c["xyz"][:1], c["resol"][:1])
+    with pytest.raises(sn.SurfaceNetHipError):
+        sn.Context(cube_D=10, max_samples=4)                               # cube_D must be a multiple of 4
+    with pytest.raises(ValueError):
+        sn.Context(cube_D=8, max_samples=4, precision="fp64")
+
+
+def test_two_contexts_and_precision_switch_are_independent(sn):
+    """Two contexts (different cube sizes / precisions) coexist; results do not depend on the order of use."""
+    values, X8, _ = _net_case(8, 2, 1, seed=1)
+    _, X16, _ = _net_case(16, 1, 1, seed=2)
+    with sn.Context(cube_D=8, max_samples=2) as a, sn.Context(cube_D=16, max_samples=2, precision="f16") as b:
+        a.load_param_values(values); b.load_param_values(values)
+        fa1, _ = a.forward(X8, None, n_vp=1)
+        fb1, _ = b.forward(X16, None, n_vp=1)
+        fa2, _ = a.forward(X8, None, n_vp=1)
+        fb2, _ = b.forward(X16, None, n_vp=1)
+        assert np.array_equal(fa1, fa2) and np.array_equal(fb1, fb2)       # deterministic, no cross-talk
+    with sn.Context(cube_D=8, max_samples=2, precision="f16") as c2:
+        c2.load_param_values(values)
+        fc, _ = c2.forward(X8, None, n_vp=1)
+    assert 0 < np.abs(fc - fa1).max() < 1e-2                               # f16 differs from f16x3, by a little
