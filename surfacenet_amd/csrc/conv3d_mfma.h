@@ -83,6 +83,8 @@ struct ConvArgs {
     int in_cs, out_cs, out_coff, out_cp;
     int D, tiles_x, tiles_y, tiles_z, total_tiles;
     int act;              // 0 relu, 1 sigmoid
+    int stagger_clk;      // start delay (shader clocks) per phase step: workgroups start in 4 phases so that their
+                          // epilogue store bursts do not hit HBM at the same instant (0 = off)
     int nslab;
     unsigned char slab_c8[kMaxSlab];  // 8-channel groups per slab
 };
@@ -179,7 +181,9 @@ struct ConvCfg {
     static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
     static constexpr int XPLANE = NSEG * 1024;
     static constexpr int XBUF = XPLANE * NPL;
-    static constexpr int LDS_BYTES = 2 * XBUF + 2 * WBUF + 2 * KOFF_N * 4;
+    static constexpr bool CST_LDS = (EPI == EPI_STORE) && NF >= 7;   // wide store epilogues: keep scale/shift in LDS so the compiler's vmcnt(0) before their use cannot serialise the stores (measured: merge_conv_a -4 %, narrower layers +3..6 % -> off there)
+    static constexpr int EPI_CONST = CST_LDS ? NF * 16 * 4 * 2 : 0;   // scale, shift of this cout split, fp32
+    static constexpr int LDS_BYTES = 2 * XBUF + 2 * WBUF + 2 * KOFF_N * 4 + EPI_CONST;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
     // two 4-wave workgroups per CU only when 256 registers per lane are plausibly enough (accumulators = MF*NF*4)
     static constexpr int WG_PER_CU = (LDS_BYTES <= 80 * 1024 && NW == 4 && MF * NF <= 32) ? 2 : 1;
@@ -197,6 +201,9 @@ conv3d_f16_mfma(ConvArgs a)
     char *const xbuf = lds;                                   // [2][NPL][XPLANE]
     char *const wbuf = lds + 2 * C::XBUF;                     // [2][WBUF]
     int *const kbuf = reinterpret_cast<int *>(lds + 2 * C::XBUF + 2 * C::WBUF);   // [2][KOFF_N]
+    // epilogue constants live in LDS: a global load in the epilogue would make hipcc wait vmcnt(0), i.e. for every store
+    // issued before it (measured: 21 us per tile of serialised store->load round trips in merge_conv_a)
+    float *const cst = reinterpret_cast<float *>(lds + 2 * C::XBUF + 2 * C::WBUF + 2 * C::KOFF_N * 4);   // [2][NF*16]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v = lane & 15, kq = lane >> 4;
@@ -211,6 +218,13 @@ conv3d_f16_mfma(ConvArgs a)
 #endif
     if (tile >= a.total_tiles) return;
 
+    if (a.stagger_clk > 0) {
+        // All workgroups do identical work per tile, so without this they stay in lockstep and write their output tiles
+        // in one chip-wide burst (measured: the store epilogue of merge_conv_a costs 18 % of the kernel that way).
+        const long long wait = (long long)((blockIdx.x >> 3) & 3) * a.stagger_clk;
+        const long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     const char *const wsrc0 = reinterpret_cast<const char *>(a.wpack + (size_t)blockIdx.y * a.wsplit_stride);
 
     // ---- helpers ---------------------------------------------------------------------------------------------
@@ -295,6 +309,11 @@ conv3d_f16_mfma(ConvArgs a)
     }
     const unsigned xbuf_a = lds_addr(xbuf), wbuf_a = lds_addr(wbuf) + lane * 16, kbuf_a = lds_addr(kbuf) + kq * 4;
 
+    if constexpr (C::CST_LDS)
+        for (int i = tid; i < NF * 16; i += C::NT) {
+            cst[i] = a.scale[blockIdx.y * NF * 16 + i];
+            cst[NF * 16 + i] = a.shift[blockIdx.y * NF * 16 + i];
+        }
     // ---- prologue: first halo tile, its tap table, first weight piece ----------------------------------------
     {
         const int c8n = a.slab_c8[0];
@@ -500,7 +519,13 @@ conv3d_f16_mfma(ConvArgs a)
         }
 
         // ---- epilogue: folded BN affine + activation --------------------------------------------------------
-        if constexpr (EPI == EPI_STORE) {
+        if constexpr (EPI == EPI_STORE && (SN_ABL & 512)) {
+            // ablation 512: keep the accumulators live, store nothing
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < NF; ++n) asm volatile("" ::"v"(acc[m][n]));
+        } else if constexpr (EPI == EPI_STORE) {
 #pragma unroll
             for (int m = 0; m < MF; ++m) {
                 const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
@@ -510,8 +535,8 @@ conv3d_f16_mfma(ConvArgs a)
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
                     if (valid && nl < a.out_cp) {
-                        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
-                        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                        const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                        const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + NF * 16 + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.shift + nl);
                         half4 h, l;
                         float lo32[4];
 #pragma unroll
@@ -549,7 +574,7 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
                     const int nl = n * 16 + kq * 4;
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);   // (no stores in flight here: global is fine)
                     const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
                     const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.w3 + nl);
 #pragma unroll

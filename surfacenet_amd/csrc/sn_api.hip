@@ -373,6 +373,17 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     // persistent workgroups: one resident set, each walking tiles blockIdx.x, +gridDim.x, ...
     const int resident = std::max(1, c->num_cus * C::WG_PER_CU / L.nsplit);
     dim3 grid((unsigned)std::min(a.total_tiles, resident), (unsigned)L.nsplit);
+    {
+        // phase-staggered start (only worthwhile when every workgroup walks many tiles): a quarter of the estimated tile time
+        static const int stag = getenv("SN_STAGGER") ? atoi(getenv("SN_STAGGER")) : 0;
+        const int tiles_per_wg = a.total_tiles / (int)grid.x;
+        if (stag && EPI == EPI_STORE && tiles_per_wg >= 8) {
+            double chunks = 0;
+            for (unsigned char c8n : L.slab_c8) chunks += (C::NTAP * c8n + 3) / 4;
+            const double units = chunks * MF * NF * (SPLIT == 1 ? 3.0 : (SPLIT == 2 ? 2.2 : 1.0));
+            a.stagger_clk = (int)(units * 19.5 * 2.0 * 1.3 / 4.0) * stag;
+        }
+    }
     hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV>), grid, dim3(NW * 64), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return SN_OK;
