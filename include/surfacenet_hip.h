@@ -121,6 +121,44 @@ int sn_cvc_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, cons
 int sn_forward_dev(sn_ctx *ctx, int n, int n_vp, const float *X_dev, const float *w_dev, float *fused_dev,
                    float *unfused_dev);
 
+/* ---- post-pass of the loop body (main_reconstruct.py:153-160) ------------------- */
+/* rayPooling.rayPooling_1cube_numpy (utils/rayPooling.py:143-260) for n cubes at once: pred (n,s,s,s) float32
+ * probabilities >= 0 (rounded to float16 inside, as append_dense_2sparseList does at utils/sparseCubes.py:136 before
+ * the call), view_pairs (n,n_vp,2) -> votes (n,s,s,s) uint8 (max 2*n_vp). use_thresh = 0 is prediction_thresh=None;
+ * otherwise voxels with fp16(pred) > fp16(min_prob) take part. Needs sn_set_cameras only. SN_ERR_ARG if a projected
+ * pixel / depth bin falls outside the int32 range (a cube on the camera plane; the reference has no such limit). */
+int sn_ray_pool(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
+                const float *pred, int use_thresh, float min_prob, unsigned char *votes);
+/* Device-resident, asynchronous; the range error is reported by the next sn_synchronize. */
+int sn_ray_pool_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
+                    const float *resol_dev, const float *pred_dev, int use_thresh, float min_prob,
+                    unsigned char *votes_dev);
+
+/* sparseCubes.dense2sparse (utils/sparseCubes.py:9-77) keyword arguments. */
+typedef struct sn_sparse_cfg {
+    float min_prob;          /* compared in float16, as numpy does for a float16 array */
+    int rayPool_thresh;
+    int enable_centerCrop;
+    int cube_Dcenter;        /* used when enable_centerCrop != 0; (s - cube_Dcenter) / 2 voxels are cut on each side */
+    int enable_rayPooling;
+} sn_sparse_cfg;
+/* pred (n,s,s,s) float32 fused probabilities, rgb (n,3,s,s,s) uint8 (sn_color_fuse's output; may be NULL) ->
+ * packed voxel lists of all cubes, cube after cube, voxels in ascending flat index of the (cropped) cube:
+ *   offsets (n+1) int64: cube i owns [offsets[i], offsets[i+1]); empty cubes have zero length (the reference skips them)
+ *   ijk (total,3) uint8 | pred16 (total) float16 bits | rgb_out (total,3) uint8 | votes_out (total) uint8
+ * Output arrays must hold n*Dc^3 entries (Dc = cube_Dcenter when cropping, else s); rgb_out / votes_out may be NULL.
+ * votes_out is filled only when enable_rayPooling. The caller shifts xyz by resol*(s-Dc)/2 (sparseCubes.py:55). */
+int sn_dense2sparse(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
+                    const float *pred, const unsigned char *rgb, const sn_sparse_cfg *cfg, int64_t *offsets,
+                    unsigned char *ijk, uint16_t *pred16, unsigned char *rgb_out, unsigned char *votes_out);
+/* Same with every array in HBM (offsets too); asynchronous. votes_ws_dev (n,s,s,s) uint8 scratch is required when
+ * enable_rayPooling. */
+int sn_dense2sparse_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
+                        const float *resol_dev, const float *pred_dev, const unsigned char *rgb_dev,
+                        const sn_sparse_cfg *cfg, unsigned char *votes_ws_dev, int64_t *offsets_dev,
+                        unsigned char *ijk_dev, uint16_t *pred16_dev, unsigned char *rgb_out_dev,
+                        unsigned char *votes_out_dev);
+
 /* ---- multi-GPU (one process per GPU): the path's only exchange is an all-gather of the per-cube fused probabilities
  * (the reference is single-GPU, no counterpart). RCCL over xGMI; librccl is dlopen'ed on first use.
  * Rank 0 calls sn_comm_unique_id and ships the 128 bytes to the other ranks by any means; every rank then calls

@@ -18,6 +18,7 @@ ABI_SYMBOLS = [
     "sn_cvc", "sn_forward", "sn_cvc_forward", "sn_relative_weights", "sn_color_fuse", "sn_color_fuse_dev",
     "sn_dev_alloc", "sn_dev_free", "sn_memcpy_h2d", "sn_memcpy_d2h",
     "sn_cvc_forward_dev", "sn_cvc_dev", "sn_forward_dev",
+    "sn_ray_pool", "sn_ray_pool_dev", "sn_dense2sparse", "sn_dense2sparse_dev",
     "sn_comm_unique_id", "sn_comm_init", "sn_allgather_f32_dev",
     "sn_profile_enable", "sn_profile_count", "sn_profile_get", "sn_profile_reset",
 ]
@@ -25,6 +26,11 @@ ABI_SYMBOLS = [
 
 class SurfaceNetHipError(RuntimeError):
     pass
+
+
+class SparseCfg(ctypes.Structure):
+    _fields_ = [("min_prob", ctypes.c_float), ("rayPool_thresh", ctypes.c_int), ("enable_centerCrop", ctypes.c_int),
+                ("cube_Dcenter", ctypes.c_int), ("enable_rayPooling", ctypes.c_int)]
 
 
 class ParamDesc(ctypes.Structure):
@@ -73,6 +79,10 @@ def load():
         "sn_cvc_forward_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 8),
         "sn_cvc_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5),
         "sn_forward_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4),
+        "sn_ray_pool": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int, ctypes.c_float, c_void_p]),
+        "sn_ray_pool_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int, ctypes.c_float, c_void_p]),
+        "sn_dense2sparse": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [P(SparseCfg)] + [c_void_p] * 5),
+        "sn_dense2sparse_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [P(SparseCfg)] + [c_void_p] * 6),
         "sn_comm_unique_id": (c_int, [ctypes.c_char_p]),
         "sn_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p]),
         "sn_allgather_f32_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -24,6 +24,7 @@ class Context(object):
         self.precision = precision
         _lib.check(self._lib.sn_set_precision(self._h, self.PRECISIONS[precision]))
         self.n_views = 0
+        self.n_cameras = 0
 
     # ---- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -69,6 +70,7 @@ class Context(object):
         if P.ndim != 3 or P.shape[1:] != (3, 4):
             raise ValueError("cameraPOs must have shape (V, 3, 4), got %s" % (P.shape,))
         _lib.check(self._lib.sn_set_cameras(self._h, P.shape[0], _lib.ptr(P)))
+        self.n_cameras = P.shape[0]
 
     # ---- hot path, host arrays --------------------------------------------------------------------
     def _batch_args(self, selected_viewPairs, xyz, resol):
@@ -147,6 +149,43 @@ class Context(object):
         return rgb
 
     # ---- hot path, device-resident ------------------------------------------------------------------
+    # ---- post-pass ----------------------------------------------------------------
+    def ray_pool(self, selected_viewPairs, xyz, resol, prediction, prediction_thresh=None):
+        """rayPooling.rayPooling_1cube_numpy (utils/rayPooling.py:143-260) for n cubes: prediction (n,s,s,s) (or
+        (n,1,s,s,s)) probabilities >= 0, compared as float16 -> votes (n,s,s,s) uint8."""
+        pairs, xyz, resol, n, n_vp = self._batch_args(selected_viewPairs, xyz, resol)
+        s = self.cube_D
+        pred = np.ascontiguousarray(np.asarray(prediction).astype(np.float16).astype(np.float32).reshape(n, s, s, s))
+        votes = np.empty((n, s, s, s), dtype=np.uint8)
+        use = 0 if prediction_thresh is None else 1
+        thr = 0.0 if prediction_thresh is None else float(np.float16(prediction_thresh))
+        _lib.check(self._lib.sn_ray_pool(self._h, n, n_vp, _lib.ptr(pairs), _lib.ptr(xyz), _lib.ptr(resol), _lib.ptr(pred), use, thr,
+                                         _lib.ptr(votes)))
+        return votes
+
+    def dense2sparse(self, prediction, rgb, selected_viewPairs, xyz, resol, min_prob=0.5, rayPool_thresh=0, enable_centerCrop=False,
+                     cube_Dcenter=None, enable_rayPooling=False):
+        """sparseCubes.dense2sparse (utils/sparseCubes.py:9-77) on the GPU. prediction (n,s,s,s) or (n,1,s,s,s) float;
+        rgb (n,3,s,s,s) uint8 or None. Returns (offsets (n+1,) int64, ijk (T,3) u8, pred (T,) f16, rgb (T,3) u8 | None,
+        votes (T,) u8 | None): cube i owns rows offsets[i]:offsets[i+1]."""
+        pairs, xyz, resol, n, n_vp = self._batch_args(selected_viewPairs, xyz, resol)
+        s = self.cube_D
+        pred = np.ascontiguousarray(np.asarray(prediction).astype(np.float16).astype(np.float32).reshape(n, s, s, s))
+        dc = int(cube_Dcenter) if enable_centerCrop else s
+        cap = n * dc ** 3
+        cfg = _lib.SparseCfg(float(np.float16(min_prob)), int(rayPool_thresh), int(bool(enable_centerCrop)), dc, int(bool(enable_rayPooling)))
+        rgb_in = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8).reshape(n, 3, s, s, s)
+        offsets = np.zeros((n + 1,), dtype=np.int64)
+        ijk = np.empty((cap, 3), dtype=np.uint8)
+        p16 = np.empty((cap,), dtype=np.float16)
+        rgb_out = None if rgb is None else np.empty((cap, 3), dtype=np.uint8)
+        votes = np.empty((cap,), dtype=np.uint8) if enable_rayPooling else None
+        _lib.check(self._lib.sn_dense2sparse(self._h, n, n_vp, _lib.ptr(pairs), _lib.ptr(xyz), _lib.ptr(resol), _lib.ptr(pred), _lib.ptr(rgb_in),
+                                             ctypes.byref(cfg), _lib.ptr(offsets), _lib.ptr(ijk), _lib.ptr(p16), _lib.ptr(rgb_out),
+                                             _lib.ptr(votes)))
+        T = int(offsets[-1])
+        return offsets, ijk[:T], p16[:T], (None if rgb_out is None else rgb_out[:T]), (None if votes is None else votes[:T])
+
     def dev_alloc(self, nbytes):
         p = self._lib.sn_dev_alloc(self._h, int(nbytes))
         if not p:

@@ -10,6 +10,7 @@ _device = 0
 _contexts = {}
 _param_values = None
 _scene_key = {}
+_cam_key = {}
 
 
 def set_device(device):
@@ -48,6 +49,18 @@ def bind_scene(ctx, cameraPOs, models_img):
     ctx.set_cameras(cams)
     ctx.set_images(models_img)
     _scene_key[id(ctx)] = key
+    _cam_key[id(ctx)] = cams.tobytes()
+
+
+def bind_cameras(ctx, cameraPOs):
+    """Cameras only (ray pooling needs no images). Changing them drops the cached scene binding."""
+    cams = np.ascontiguousarray(cameraPOs, dtype=np.float64)
+    key = cams.tobytes()
+    if _cam_key.get(id(ctx)) == key:
+        return
+    ctx.set_cameras(cams)
+    _cam_key[id(ctx)] = key
+    _scene_key.pop(id(ctx), None)
 
 
 def reset():
@@ -55,3 +68,4 @@ def reset():
         ctx.close()
     _contexts.clear()
     _scene_key.clear()
+    _cam_key.clear()
