@@ -75,6 +75,51 @@ def fast_mode(surfacenet_amd, scene, values, s, n, n_vp, device, steps):
             "note": "operands rounded to fp16: L_inf vs fp64 oracle 1e-3..4e-3 on BN-calibrated nets (above the 1e-3 bar) - not the headline"}
 
 
+def post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, steps, keep_frac=0.1):
+    """Extra, non-headline measurement: the whole loop body of main_reconstruct.py:134-160 --
+    hot path + voxel colours + ray pooling + dense2sparse -- device-resident (reconstruct.SparseLoop), packed sparse
+    lists copied to the host every step. min_prob is set at the (1-keep_frac) quantile of the synthetic net's outputs
+    so that keep_frac of the voxels survive (random weights have no surfaces; ~10% is a thick one)."""
+    from surfacenet_amd import reconstruct
+    from oracle import post_oracle
+    fused, _, _ = ctx.cvc_forward(scene["pairs"][:4], scene["xyz"][:4], scene["resol"][:4], scene["w"][:4], return_unfused=False)
+    p16 = fused.astype(np.float16)[:, 0]
+    dc = {32: 26, 64: 52}.get(s, s)                       # params.py: __cube_Dcenter = {32:26, 64:52}
+    lo = (s - dc) // 2
+    core = p16[:, lo:lo + dc, lo:lo + dc, lo:lo + dc]     # the centre crop is what dense2sparse keeps
+    vals, cnt = np.unique(core, return_counts=True)                # float16 outputs have few distinct values: pick the one whose
+    above = 1.0 - np.cumsum(cnt) / float(core.size)               # strict ">" keeps closest to keep_frac of the voxels
+    thr = float(vals[int(np.argmin(np.abs(above - keep_frac)))])
+    loop = reconstruct.SparseLoop(ctx, n_vp, max_cubes=n, min_prob=thr, rayPool_thresh=0, enable_centerCrop=True, cube_Dcenter=dc,
+                                  enable_rayPooling=True)
+    args = (scene["pairs"], scene["xyz"], scene["resol"], scene["w"])
+    res = loop.run(*args)
+    ctx.synchronize()
+    ctx.profile_reset(); ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = loop.run(*args)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = ctx.profile(); ctx.profile_enable(False); ctx.profile_reset()
+    loop.close()
+    kept = int(sum(len(x) for x in res[2]))
+    t0 = time.perf_counter()                              # CPU: the oracle's ray pooling on the same first cubes
+    for i in range(4):
+        post_oracle.ray_pool_1cube(scene["cams"], p16[i], scene["pairs"][i], scene["xyz"][i], scene["resol"][i], thr)
+    t_cpu = (time.perf_counter() - t0) / 4
+    rp, d2 = prof.get("ray_pool"), prof.get("dense2sparse")
+    out = {"value": round(n / dt, 2), "unit": "cubes/s", "what": "CVC+CNN+fusion+colour fusion+ray pooling+dense2sparse, sparse lists to host each step",
+           "ms_per_step": round(dt * 1e3, 3), "min_prob": round(thr, 4), "kept_voxels_per_cube": round(kept / float(n), 1),
+           "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if k in ("ray_pool", "dense2sparse", "color_fuse")},
+           "cpu_ray_pool_ms_per_cube": round(t_cpu * 1e3, 2)}
+    if rp:
+        out["ray_pool_GBps"] = round(rp["bytes"] / (rp["ms"] * 1e-3) / 1e9, 1)
+    if d2:
+        out["dense2sparse_GBps"] = round(d2["bytes"] / (d2["ms"] * 1e-3) / 1e9, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +132,7 @@ def main():
                     help="f16x3 (default): hi/lo split fp16 operands, fp32-class results (parity grade); f16: fast mode, L_inf ~2e-3")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16 fast-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-post-pass", action="store_true", help="skip the extra whole-loop-body (ray pooling / dense2sparse) measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -206,6 +252,8 @@ def main():
                                    "FLOP, so its ceiling is frac = 1/3" if args.precision == "f16x3" else "achieved = algorithmic conv FLOPs / kernel time")
         if world == 1 and args.precision == "f16x3" and not args.no_fast_mode:
             out["fast_mode_f16"] = fast_mode(surfacenet_amd, scene, values, s, n, n_vp, local_rank, max(3, args.steps // 2))
+        if world == 1 and not args.no_post_pass:
+            out["loop_body_with_post_pass"] = post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, max(3, args.steps // 2))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, values, s, n_vp)
         print(json.dumps(out))

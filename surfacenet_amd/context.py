@@ -215,6 +215,23 @@ class Context(object):
         _lib.check(self._lib.sn_cvc_forward_dev(self._h, n, n_vp, pairs_dev, xyz_dev, resol_dev, _lib.ptr(m), w_dev, fused_dev,
                                                 unfused_dev, cvc_out_dev))
 
+    def color_fuse_dev(self, n, n_vp, cvc_dev, unfused_dev, w_dev, rgb_dev, mean=MEAN_CVC_RGBRGB):
+        m = np.ascontiguousarray(mean, dtype=np.float32).reshape(6)
+        _lib.check(self._lib.sn_color_fuse_dev(self._h, n, n_vp, cvc_dev, _lib.ptr(m), unfused_dev, w_dev, rgb_dev))
+
+    def ray_pool_dev(self, n, n_vp, pairs_dev, xyz_dev, resol_dev, pred_dev, votes_dev, prediction_thresh=None):
+        use = 0 if prediction_thresh is None else 1
+        thr = 0.0 if prediction_thresh is None else float(np.float16(prediction_thresh))
+        _lib.check(self._lib.sn_ray_pool_dev(self._h, n, n_vp, pairs_dev, xyz_dev, resol_dev, pred_dev, use, thr, votes_dev))
+
+    def dense2sparse_dev(self, n, n_vp, pairs_dev, xyz_dev, resol_dev, pred_dev, rgb_dev, votes_ws_dev, offsets_dev, ijk_dev, pred16_dev,
+                         rgb_out_dev, votes_out_dev, min_prob=0.5, rayPool_thresh=0, enable_centerCrop=False, cube_Dcenter=None,
+                         enable_rayPooling=False):
+        dc = int(cube_Dcenter) if enable_centerCrop else self.cube_D
+        cfg = _lib.SparseCfg(float(np.float16(min_prob)), int(rayPool_thresh), int(bool(enable_centerCrop)), dc, int(bool(enable_rayPooling)))
+        _lib.check(self._lib.sn_dense2sparse_dev(self._h, n, n_vp, pairs_dev, xyz_dev, resol_dev, pred_dev, rgb_dev, ctypes.byref(cfg),
+                                                 votes_ws_dev, offsets_dev, ijk_dev, pred16_dev, rgb_out_dev, votes_out_dev))
+
     # ---- multi-GPU exchange (RCCL, native; torch.distributed is not required) ---------------------------
     @staticmethod
     def comm_unique_id():

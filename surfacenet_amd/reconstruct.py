@@ -4,6 +4,9 @@
 * `hot_loop`               generator with the loop body's contract: per batch selector it yields
                            (surfacePrediction, unfused_predictions, CVC + mean) exactly as lines 134-150 produce them
 * `infer_cubes`            the same work for a plain list of cubes, fused CVC->CNN->fusion per batch
+* `SparseLoop`             the WHOLE loop body (main_reconstruct.py:134-160: CVC -> CNN -> fusion -> voxel colours ->
+                           ray pooling -> dense2sparse) device-resident: only cube parameters go up and only the packed
+                           sparse voxel lists come down
 * `shard_bounds`, `infer_cubes_sharded`  cubes are independent: contiguous ranges per rank, no data-path
                            collective; ONE all-gather of the fused probabilities at the end (RCCL over xGMI when the
                            process group is "nccl"; gloo on CPU in the tests)
@@ -54,6 +57,75 @@ def infer_cubes(ctx, viewPairs, xyz, resol, w=None, batch_size=None):
         f, _, _ = ctx.cvc_forward(viewPairs[i0:i1], xyz[i0:i1], resol[i0:i1], None if w is None else w[i0:i1], return_unfused=False)
         out[i0:i1] = f
     return out
+
+
+class SparseLoop(object):
+    """Device-resident form of one loop iteration of main_reconstruct.py:132-160 for up to `max_cubes` cubes per call.
+
+    run(viewPairs (n,N_vp,2), xyz (n,3), resol (n,), w (n,N_vp)) returns what `sparseCubes.dense2sparse` returns for
+    the batch: (nonempty_cube_indx, vxl_ijk_list, prediction_list, rgb_list, rayPooling_votes_list, xyz_new) with the
+    keyword settings given at construction (defaults = the reference's call: min_prob params.__min_prob, rayPool_thresh 0,
+    centre crop on, ray pooling on)."""
+
+    def __init__(self, ctx, n_vp, max_cubes=None, min_prob=0.5, rayPool_thresh=0, enable_centerCrop=True, cube_Dcenter=None,
+                 enable_rayPooling=True, mean=MEAN_CVC_RGBRGB):
+        self.ctx, self.n_vp = ctx, int(n_vp)
+        s = ctx.cube_D
+        self.max_cubes = int(max_cubes or max(1, ctx.max_samples // self.n_vp))
+        if self.max_cubes * self.n_vp > ctx.max_samples:
+            raise ValueError("max_cubes * n_vp exceeds the context's max_samples")
+        self.cfg = dict(min_prob=min_prob, rayPool_thresh=rayPool_thresh, enable_centerCrop=enable_centerCrop,
+                        cube_Dcenter=(cube_Dcenter if enable_centerCrop else None), enable_rayPooling=enable_rayPooling)
+        self.dc = int(cube_Dcenter) if enable_centerCrop else s
+        self.lo = (s - self.dc) // 2
+        self.mean = np.ascontiguousarray(mean, dtype=np.float32)
+        N, S, v = self.max_cubes, self.max_cubes * self.n_vp, s ** 3
+        cap = N * self.dc ** 3
+        A = ctx.dev_alloc
+        self.d = dict(pairs=A(S * 16), xyz=A(N * 12), resol=A(N * 4), w=A(S * 4), fused=A(N * v * 4), unfused=A(S * v * 4),
+                      cvc=A(S * 6 * v * 4), rgb=A(N * 3 * v), votes=A(N * v), offsets=A((N + 1) * 8), ijk=A(cap * 3), p16=A(cap * 2),
+                      rgb_out=A(cap * 3), votes_out=A(cap))
+        self._off = np.zeros((N + 1,), dtype=np.int64)
+
+    def close(self):
+        for p in self.d.values():
+            self.ctx.dev_free(p)
+        self.d = {}
+
+    def run(self, viewPairs, xyz, resol, w=None):
+        ctx, d, n_vp = self.ctx, self.d, self.n_vp
+        pairs = np.ascontiguousarray(viewPairs, dtype=np.int64)
+        n = pairs.shape[0]
+        if pairs.shape[1:] != (n_vp, 2) or n > self.max_cubes:
+            raise ValueError("viewPairs must have shape (n <= %d, %d, 2)" % (self.max_cubes, n_vp))
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(n, 3)
+        resol = np.ascontiguousarray(resol, dtype=np.float32).reshape(n)
+        xyz_new = xyz + (resol[:, None] * self.lo).astype(np.float32) if self.cfg["enable_centerCrop"] else xyz.copy()
+        if n == 0:
+            return [], [], [], [], [], xyz_new
+        V = ctx.n_views
+        if pairs.max() >= V or pairs.min() < -V:
+            raise IndexError("view index out of range for %d views" % V)
+        pairs = np.where(pairs < 0, pairs + V, pairs)
+        w = np.full((n, n_vp), 1.0 / n_vp, np.float32) if w is None else np.ascontiguousarray(w, dtype=np.float32).reshape(n, n_vp)
+        ctx.h2d(d["pairs"], pairs); ctx.h2d(d["xyz"], xyz); ctx.h2d(d["resol"], resol); ctx.h2d(d["w"], w)
+        ctx.cvc_forward_dev(n, n_vp, d["pairs"], d["xyz"], d["resol"], d["w"], d["fused"], d["unfused"], d["cvc"], mean=self.mean)
+        ctx.color_fuse_dev(n, n_vp, d["cvc"], d["unfused"], d["w"], d["rgb"], mean=self.mean)      # main_reconstruct.py:150-152
+        ctx.dense2sparse_dev(n, n_vp, d["pairs"], d["xyz"], d["resol"], d["fused"], d["rgb"], d["votes"], d["offsets"], d["ijk"], d["p16"],
+                             d["rgb_out"], d["votes_out"], **self.cfg)                                 # :153-160
+        off = self._off[:n + 1]
+        ctx.d2h(off, d["offsets"])
+        ctx.synchronize()
+        T = int(off[-1])
+        ijk = np.empty((T, 3), np.uint8); p16 = np.empty((T,), np.float16); rgb = np.empty((T, 3), np.uint8)
+        votes = np.empty((T,), np.uint8) if self.cfg["enable_rayPooling"] else None
+        if T:
+            ctx.d2h(ijk, d["ijk"]); ctx.d2h(p16, d["p16"]); ctx.d2h(rgb, d["rgb_out"])
+            if votes is not None:
+                ctx.d2h(votes, d["votes_out"])
+        nonempty = [int(i) for i in np.nonzero(np.diff(off))[0]]
+        cut = lambda a: [a[off[i]:off[i + 1]] for i in nonempty]
+        return nonempty, cut(ijk), cut(p16), cut(rgb), (cut(votes) if votes is not None else []), xyz_new
 
 
 def shard_bounds(n, world, rank):

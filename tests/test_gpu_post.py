@@ -163,3 +163,37 @@ def test_post_error_paths(sn):
     want = post_oracle.ray_pool_1cube(P_DTU, pred[0].astype(np.float16), np.asarray([[0, 1]]), [0, 0, 600.0], 0.4, 0.5)
     assert np.array_equal(v, want)
     runtime.reset()
+
+
+@pytest.mark.parametrize("n_vp,crop", [(2, True), (1, False)])
+def test_sparse_loop_device_chain_equals_piecewise(sn, n_vp, crop):
+    """reconstruct.SparseLoop (CVC -> CNN -> fusion -> colours -> ray pooling -> dense2sparse without leaving HBM)
+    == the same steps through the host-array entry points, checked against the oracle's dense2sparse."""
+    import golden_util
+    import synth
+    from surfacenet_amd import reconstruct
+    s, n = 16, 5
+    sc = golden_util.synthetic_scene(n, n_vp, s=s, seed=11, hw=(600, 800))
+    values = list(synth.calibrated_params(1))
+    # the synthetic net's probabilities hover around its calibration mean: threshold at their median so ~half survive
+    with sn.Context(cube_D=s, max_samples=16) as ctx:
+        ctx.load_param_values(values)
+        ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        fused, unfused, cvc = ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"], sc["w"], return_cvc=True)
+        rgb = ctx.color_fuse(cvc, unfused, sc["w"])
+        thr = float(np.median(fused.astype(np.float16)))
+        loop = reconstruct.SparseLoop(ctx, n_vp, min_prob=thr, rayPool_thresh=0, enable_centerCrop=crop, cube_Dcenter=12 if crop else None,
+                                      enable_rayPooling=True)
+        got = loop.run(sc["pairs"], sc["xyz"], sc["resol"], sc["w"])
+        got2 = loop.run(sc["pairs"][:2], sc["xyz"][:2], sc["resol"][:2], sc["w"][:2])      # buffers are reusable, shorter batch
+        loop.close()
+    p16, rgb8 = post_oracle.to_sparse_inputs(fused, rgb)
+    want = post_oracle.dense2sparse(p16, rgb8, sc["xyz"], sc["resol"], sc["pairs"], min_prob=thr, rayPool_thresh=0, enable_centerCrop=crop,
+                                    cube_Dcenter=12 if crop else None, enable_rayPooling=True, cameraPOs=sc["cams"])
+    assert got[0] == want[0] and len(want[0]) > 0
+    for k in (1, 3, 4):
+        assert all(np.array_equal(a, b) for a, b in zip(got[k], want[k])), k
+    assert all(np.array_equal(a.view(np.uint16), b.view(np.uint16)) for a, b in zip(got[2], want[2]))
+    assert np.array_equal(got[5], want[5])
+    assert got2[0] == [i for i in want[0] if i < 2]
+    assert all(np.array_equal(a, b) for a, b in zip(got2[1], want[1]))
