@@ -7,6 +7,9 @@
 * `SparseLoop`             the WHOLE loop body (main_reconstruct.py:134-160: CVC -> CNN -> fusion -> voxel colours ->
                            ray pooling -> dense2sparse) device-resident: only cube parameters go up and only the packed
                            sparse voxel lists come down
+* `gather_sparse_sharded`   the multi-GPU exchange when the post-pass runs on the GPU: every rank holds only the packed
+                           sparse voxel lists of its cube shard (9 B per kept voxel instead of 4 B x s^3 per cube); two
+                           all-gathers (lengths, then one padded byte buffer) rebuild the global lists on every rank
 * `shard_bounds`, `infer_cubes_sharded`  cubes are independent: contiguous ranges per rank, no data-path
                            collective; ONE all-gather of the fused probabilities at the end (RCCL over xGMI when the
                            process group is "nccl"; gloo on CPU in the tests)
@@ -150,3 +153,52 @@ def infer_cubes_sharded(compute_fn, n, s, group=None, device=None):
     full = torch.empty((world * per, 1, s, s, s), dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(full, local, group=group)
     return full[:n].cpu().numpy()
+
+
+def gather_sparse_sharded(local, lo, group=None, device=None):
+    """`local` = dense2sparse's tuple for this rank's cube shard [lo, hi) (indices in `local[0]` are shard-relative).
+    Returns the same tuple for ALL cubes on every rank (global cube indices, rank order = cube order). Wire format per
+    rank: int64 header (n_cubes, then per cube: global index, voxel count) + packed ijk | pred16 | rgb | votes bytes."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    nonempty, ijk_l, p_l, rgb_l, v_l, xyz_new = local
+    counts = np.asarray([len(x) for x in p_l], dtype=np.int64)
+    head = np.concatenate([[len(nonempty), int(bool(len(v_l)) or len(p_l) == 0)], np.asarray(nonempty, dtype=np.int64) + lo, counts]).astype(np.int64)
+    cat = lambda lst, dt, tail: (np.concatenate(lst) if len(lst) else np.zeros((0,) + tail, dt)).astype(dt, copy=False)
+    body = [cat(ijk_l, np.uint8, (3,)).reshape(-1), cat(p_l, np.float16, ()).view(np.uint8).reshape(-1), cat(rgb_l, np.uint8, (3,)).reshape(-1)]
+    if len(v_l):
+        body.append(cat(v_l, np.uint8, ()).reshape(-1))
+    xyz_b = np.ascontiguousarray(xyz_new, dtype=np.float32).view(np.uint8).reshape(-1)
+    blob = np.concatenate([np.asarray([head.size, xyz_b.size], np.int64).view(np.uint8), head.view(np.uint8), xyz_b] + body)
+    sizes = torch.zeros((world,), dtype=torch.int64, device=device)
+    mine = torch.tensor([blob.size], dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, mine, group=group)
+    cap = int(sizes.max().item())
+    buf = torch.zeros((cap,), dtype=torch.uint8, device=device)
+    buf[: blob.size] = torch.from_numpy(blob).to(buf.device)
+    allb = torch.empty((world * cap,), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(allb, buf, group=group)
+    allb = allb.cpu().numpy()
+    out = ([], [], [], [], [], [])
+    for r in range(world):
+        b = allb[r * cap: r * cap + int(sizes[r].item())]
+        nh, nx = (int(v) for v in b[:16].view(np.int64))
+        h = b[16:16 + 8 * nh].view(np.int64)
+        o = 16 + 8 * nh
+        out[5].append(b[o:o + nx].view(np.float32).reshape(-1, 3))
+        o += nx
+        k, votes_on = int(h[0]), bool(h[1])
+        idx, cnt = h[2:2 + k], h[2 + k:2 + 2 * k]
+        T = int(cnt.sum())
+        ijk = b[o:o + 3 * T].reshape(T, 3); o += 3 * T
+        p16 = b[o:o + 2 * T].view(np.float16); o += 2 * T
+        rgb = b[o:o + 3 * T].reshape(T, 3); o += 3 * T
+        votes = b[o:o + T] if votes_on else None
+        ends = np.cumsum(cnt)
+        for j in range(k):
+            a, e = int(ends[j] - cnt[j]), int(ends[j])
+            out[0].append(int(idx[j])); out[1].append(ijk[a:e].copy()); out[2].append(p16[a:e].copy()); out[3].append(rgb[a:e].copy())
+            if votes is not None:
+                out[4].append(votes[a:e].copy())
+    return out[0], out[1], out[2], out[3], out[4], np.concatenate(out[5], axis=0)

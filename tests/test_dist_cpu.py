@@ -44,3 +44,53 @@ def test_sharded_inference_allgather_gloo(n):
         assert vals == [i + 0.25 for i in range(n)]                       # every rank holds every cube, in order
         lo, hi = min(n, rank * per), min(n, rank * per + per)
         assert calls == ([(lo, hi)] if hi > lo else [])                   # each rank computed only its own shard
+
+
+def _sparse_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from surfacenet_amd import reconstruct
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = reconstruct.shard_bounds(n, world, rank)
+    local = _fake_sparse(lo, hi)                      # stand-in for SparseLoop.run on this rank's shard
+    full = reconstruct.gather_sparse_sharded(local, lo)
+    q.put((rank, full))
+    dist.destroy_process_group()
+
+
+def _fake_sparse(lo, hi):
+    """Deterministic sparse lists for cubes [lo, hi): cube g keeps (g*7) % 5 voxels (so some cubes are empty)."""
+    ne, ijk, p, rgb, v = [], [], [], [], []
+    for g in range(lo, hi):
+        k = (g * 7) % 5
+        if k == 0:
+            continue
+        rs = np.random.RandomState(g)
+        ne.append(g - lo)
+        ijk.append(rs.randint(0, 26, (k, 3)).astype(np.uint8)); p.append(rs.rand(k).astype(np.float16))
+        rgb.append(rs.randint(0, 256, (k, 3)).astype(np.uint8)); v.append(rs.randint(0, 5, k).astype(np.uint8))
+    xyz = np.arange(lo, hi, dtype=np.float32)[:, None] * np.ones((1, 3), np.float32)
+    return ne, ijk, p, rgb, v, xyz
+
+
+@pytest.mark.parametrize("n", [7, 2, 1])
+def test_sparse_lists_exchange_gloo(n):
+    """N>1 path of the GPU post-pass: ranks exchange packed sparse voxel lists, not dense probability cubes."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _fake_sparse(0, n)
+    for rank, full in res:
+        assert full[0] == want[0]
+        for k in (1, 2, 3, 4):
+            assert len(full[k]) == len(want[k]) and all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(full[k], want[k])), k
+        assert np.array_equal(full[5], want[5])
