@@ -159,6 +159,25 @@ int sn_dense2sparse_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_
                         unsigned char *ijk_dev, uint16_t *pred16_dev, unsigned char *rgb_out_dev,
                         unsigned char *votes_out_dev);
 
+/* ---- similarityNet / early rejection (main_reconstruct.py:76-97) ---------------- */
+/* pickle.load + set_all_param_values([embedding layer, similarity layer]) of similarityNet_inference
+ * (nets/similarityNet.py:229-244): 30 arrays in order — 13 x (conv W (Cout,Cin,3,3), b (Cout,)) for conv1_1 .. conv5_3
+ * (cross-correlation, as Conv2DDNNLayer), embedding W (5888,128), b (128,), similarity W (1,1), b (1,). */
+int sn_simil_load_weights(sn_ctx *ctx, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params);
+/* image.cropImgPatches(img = view's image, pyramidRate = 1, cubeCenter_hw = (center_h, center_w)) (utils/image.py:92-183, as
+ * called at utils/earlyRejection.py:50): n patches (n,64,64,3) uint8 RGB around the truncated centre projections,
+ * coordinates clamped to the image. center_h / center_w: float64 (n,). Needs sn_set_images. */
+int sn_crop_patches(sn_ctx *ctx, int view, int n, const double *center_h, const double *center_w, unsigned char *patches);
+/* patch2embedding_fn (nets/similarityNet.py:219-221): preprocessed patches (n,3,64,64) float32 (BGR - mean) -> (n,128). */
+int sn_patch2embedding(sn_ctx *ctx, int n, const float *patches, float *embeddings);
+/* The inner loop of earlyRejection.patch2embedding (utils/earlyRejection.py:50-53) without leaving HBM: crop +
+ * image.preprocess_patches (utils/image.py:9-36, mean_bgr[3]) + patch2embedding_fn for n cube centres of one view. */
+int sn_crop_embed(sn_ctx *ctx, int view, int n, const double *center_h, const double *center_w, const float *mean_bgr,
+                  float *embeddings);
+/* embeddingPair2simil_fn (nets/similarityNet.py:223-226): rows 2i, 2i+1 of emb_pairs (2*n_pairs,128) -> (n_pairs,1)
+ * sigmoid(w * ||e1 - e2||_2 + b). */
+int sn_embeddingpair2simil(sn_ctx *ctx, int n_pairs, const float *emb_pairs, float *similarity);
+
 /* ---- multi-GPU (one process per GPU): the path's only exchange is an all-gather of the per-cube fused probabilities
  * (the reference is single-GPU, no counterpart). RCCL over xGMI; librccl is dlopen'ed on first use.
  * Rank 0 calls sn_comm_unique_id and ships the 128 bytes to the other ranks by any means; every rank then calls

@@ -149,6 +149,48 @@ class Context(object):
         return rgb
 
     # ---- hot path, device-resident ------------------------------------------------------------------
+    # ---- similarityNet / early rejection -------------------------------------------
+    def load_simil_param_values(self, values):
+        """values: the similarityNet weight file's 30 arrays (weights.SIMIL_PARAM_SHAPES order)."""
+        blob, descs = _weights.simil_to_blob(values)
+        _lib.check(self._lib.sn_simil_load_weights(self._h, _lib.ptr(blob), blob.size, descs, len(values)))
+
+    def crop_patches(self, view, center_h, center_w):
+        """image.cropImgPatches(img=images[view], pyramidRate=1, cubeCenter_hw=(center_h, center_w)) -> (n,64,64,3) uint8."""
+        ch = np.ascontiguousarray(center_h, dtype=np.float64).reshape(-1)
+        cw = np.ascontiguousarray(center_w, dtype=np.float64).reshape(-1)
+        out = np.empty((ch.size, 64, 64, 3), dtype=np.uint8)
+        _lib.check(self._lib.sn_crop_patches(self._h, int(view), ch.size, _lib.ptr(ch), _lib.ptr(cw), _lib.ptr(out)))
+        return out
+
+    def patch2embedding(self, patches):
+        """patch2embedding_fn: preprocessed (n,3,64,64) float32 patches -> (n,128) float32 embeddings."""
+        if not isinstance(patches, np.ndarray) or patches.dtype != np.float32 or patches.ndim != 4 or patches.shape[1:] != (3, 64, 64):
+            raise TypeError("patches must be a float32 ndarray of shape (n, 3, 64, 64)")
+        x = np.ascontiguousarray(patches)
+        out = np.empty((x.shape[0], _weights.D_EMBEDDING), dtype=np.float32)
+        _lib.check(self._lib.sn_patch2embedding(self._h, x.shape[0], _lib.ptr(x), _lib.ptr(out)))
+        return out
+
+    def crop_embed(self, view, center_h, center_w, mean_bgr):
+        """crop + preprocess + embedding of n cube centres of one view without leaving HBM -> (n,128)."""
+        ch = np.ascontiguousarray(center_h, dtype=np.float64).reshape(-1)
+        cw = np.ascontiguousarray(center_w, dtype=np.float64).reshape(-1)
+        m = np.ascontiguousarray(mean_bgr, dtype=np.float32).reshape(3)
+        out = np.empty((ch.size, _weights.D_EMBEDDING), dtype=np.float32)
+        _lib.check(self._lib.sn_crop_embed(self._h, int(view), ch.size, _lib.ptr(ch), _lib.ptr(cw), _lib.ptr(m), _lib.ptr(out)))
+        return out
+
+    def embeddingpair2simil(self, emb_pairs):
+        """embeddingPair2simil_fn: (2n,128) float32 (rows 2i, 2i+1 = pair i) -> (n,1) float32."""
+        if not isinstance(emb_pairs, np.ndarray) or emb_pairs.dtype != np.float32 or emb_pairs.ndim != 2 or emb_pairs.shape[1] != _weights.D_EMBEDDING \
+                or emb_pairs.shape[0] % 2:
+            raise TypeError("embeddingPair must be a float32 matrix (2n, %d)" % _weights.D_EMBEDDING)
+        e = np.ascontiguousarray(emb_pairs)
+        out = np.empty((e.shape[0] // 2, 1), dtype=np.float32)
+        _lib.check(self._lib.sn_embeddingpair2simil(self._h, e.shape[0] // 2, _lib.ptr(e), _lib.ptr(out)))
+        return out
+
     # ---- post-pass (SURVEY §8f row N2) ----------------------------------------------------------------
     def ray_pool(self, selected_viewPairs, xyz, resol, prediction, prediction_thresh=None):
         """rayPooling.rayPooling_1cube_numpy (utils/rayPooling.py:143-260) for n cubes: prediction (n,s,s,s) (or

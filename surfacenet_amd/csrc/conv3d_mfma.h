@@ -81,7 +81,7 @@ struct ConvArgs {
     long long wsplit_stride;  // halfs between channel splits in wpack
     long long in_lo_off, out_lo_off;
     int in_cs, out_cs, out_coff, out_cp;
-    int D, tiles_x, tiles_y, tiles_z, total_tiles;
+    int D, DX, tiles_x, tiles_y, tiles_z, total_tiles;   // volume = DX x D x D voxels (3-D nets: DX = D; 2-D nets: x = image index)
     int act;              // 0 relu, 1 sigmoid
     int stagger_clk;      // start delay (shader clocks) per phase step: workgroups start in 4 phases so that their
                           // epilogue store bursts do not hit HBM at the same instant (0 = off)
@@ -157,14 +157,15 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_dst_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_dst_wave_base, 16, 0, AUX);
 }
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_>
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_, int K2D = 0>
 struct ConvCfg {
     static constexpr int R = (KS / 2) * DIL;
+    static constexpr int RX = K2D ? 0 : R;                 // K2D: KSxKS taps over (y,z) only; x (the image index) has no halo
     static constexpr int XS = MF / 4;                      // x-slices per wave
     static constexpr int NW = NW_;                         // waves per workgroup
     static constexpr int NT = NW * 64;
     static constexpr int TX = NW * XS, TY = 8, TZ = 8;
-    static constexpr int HX = TX + 2 * R, HY = TY + 2 * R, HZ = TZ + 2 * R;
+    static constexpr int HX = TX + 2 * RX, HY = TY + 2 * R, HZ = TZ + 2 * R;
     static constexpr int HVOX = HX * HY * HZ;
     static constexpr int CS8MAX = CS8;                     // 8-channel groups per slab
     static constexpr int SLOTS = CS8 + PADV_;              // 16-byte slots per halo voxel (PADV: one pad slot)
@@ -176,7 +177,7 @@ struct ConvCfg {
     static constexpr int MFRAG = 1024 * NPLM;              // bytes of one f16 weight fragment set (hi [+ lo])
     static_assert(SPLIT != 2 || PCH_ == 2, "f16m8: a weight piece is 2 K-chunks + one MX step");
     static constexpr int WBUF = PCH * NF * FRAG;
-    static constexpr int NTAP = KS * KS * KS;
+    static constexpr int NTAP = (K2D ? 1 : KS) * KS * KS;
     static constexpr int KOFF_N = NTAP * CS8MAX + 20;      // + look-ahead padding (2 chunks; f16m8: one 8-group piece)
     static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
     static constexpr int XPLANE = NSEG * 1024;
@@ -191,11 +192,11 @@ struct ConvCfg {
     static constexpr int MIN_WAVES_PER_SIMD = (NW == 8 || WG_PER_CU == 2) ? 2 : 1;
 };
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_>
-__global__ void __launch_bounds__(NW_ * 64, (ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_, PADV_>::MIN_WAVES_PER_SIMD))
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_, int K2D = 0>
+__global__ void __launch_bounds__(NW_ * 64, (ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_, PADV_, K2D>::MIN_WAVES_PER_SIMD))
 conv3d_f16_mfma(ConvArgs a)
 {
-    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_, PADV_>;
+    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_, PADV_, K2D>;
     constexpr int NPL = C::NPL;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     char *const xbuf = lds;                                   // [2][NPL][XPLANE]
@@ -207,7 +208,8 @@ conv3d_f16_mfma(ConvArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v = lane & 15, kq = lane >> 4;
-    const int D = a.D;
+    const int D = a.D, DX = a.DX;
+    const size_t VOL = (size_t)DX * D * D;
     const int tstride = gridDim.x;
 #if SN_XCD_REMAP
     // XCD-aware walk (speed only): workgroup i is observed to run on XCD i % 8; within each round of gridDim.x tiles XCD x
@@ -242,7 +244,7 @@ conv3d_f16_mfma(ConvArgs a)
     auto stage_halo = [&](int t, int c0, int c8n, int xb, int k0, int kn) -> int {
         int b, x0, y0, z0;
         tile_origin(t, b, x0, y0, z0);
-        const _Float16 *in_b = a.in + (size_t)b * D * D * D * a.in_cs;
+        const _Float16 *in_b = a.in + (size_t)b * VOL * a.in_cs;
         int issued = 0;
         for (int k = k0; k < k0 + kn; ++k) {
             const int li = k * C::NW + wave;
@@ -251,10 +253,10 @@ conv3d_f16_mfma(ConvArgs a)
             const int slot = seg * 64 + lane;
             const int hv = slot / C::SLOTS, part = slot - hv * C::SLOTS;
             const int hz = hv % C::HZ, hy = (hv / C::HZ) % C::HY, hx = hv / (C::HZ * C::HY);
-            const int gx = x0 - C::R + hx, gy = y0 - C::R + hy, gz = z0 - C::R + hz;
-            const bool ok = part < c8n && hv < C::HVOX && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D &&
+            const int gx = x0 - C::RX + hx, gy = y0 - C::R + hy, gz = z0 - C::R + hz;
+            const bool ok = part < c8n && hv < C::HVOX && (unsigned)gx < (unsigned)DX && (unsigned)gy < (unsigned)D &&
                             (unsigned)gz < (unsigned)D;
-            const _Float16 *p = in_b + ((size_t)(c0 + part) * D * D * D + ((size_t)(gx * D + gy) * D + gz)) * 8 + (pl ? a.in_lo_off : 0);
+            const _Float16 *p = in_b + ((size_t)(c0 + part) * VOL + ((size_t)(gx * D + gy) * D + gz)) * 8 + (pl ? a.in_lo_off : 0);
             dma16<SN_HALO_AUX>(ok ? (const void *)p : a.zero_page, xbuf + xb * C::XBUF + pl * C::XPLANE + seg * 1024);
             ++issued;
         }
@@ -529,7 +531,7 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
             for (int m = 0; m < MF; ++m) {
                 const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
-                const bool valid = gx < D && gy < D && gz < D;
+                const bool valid = gx < DX && gy < D && gz < D;
                 const size_t vlin = ((size_t)gx * D + gy) * D + gz;
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
@@ -553,7 +555,7 @@ conv3d_f16_mfma(ConvArgs a)
                             }
                         }
                         const int ch = a.out_coff + nl;   // group-blocked layout: [b][ch/8][x][y][z][ch%8]
-                        _Float16 *o = a.out + (size_t)b * D * D * D * a.out_cs + ((size_t)(ch >> 3) * D * D * D + vlin) * 8 + (ch & 7);
+                        _Float16 *o = a.out + (size_t)b * VOL * a.out_cs + ((size_t)(ch >> 3) * VOL + vlin) * 8 + (ch & 7);
                         *reinterpret_cast<half4 *>(o) = h;
                         if constexpr (SPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
                         if constexpr (SPLIT == 2) {
@@ -581,8 +583,8 @@ conv3d_f16_mfma(ConvArgs a)
                     for (int r = 0; r < 4; ++r) p += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
                 }
                 const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
-                const bool valid = gx < D && gy < D && gz < D;
-                const size_t vox = ((size_t)(b * D + gx) * D + gy) * D + gz;
+                const bool valid = gx < DX && gy < D && gz < D;
+                const size_t vox = ((size_t)(b * DX + gx) * D + gy) * D + gz;
                 p += __shfl_xor(p, 16);
                 p += __shfl_xor(p, 32);
                 if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(p * a.scale3 + a.shift3);

@@ -1,0 +1,162 @@
+// simil.h — glue kernels of the similarityNet / early-rejection stage. The 13 convolutions run on
+// conv3d_f16_mfma<..., K2D = 1> (conv3d_mfma.h): a batch of N patches is the volume (x = patch index, y, z = pixel
+// row, column), activations in the same 8-channel-group layout act[c/8][n][h][w][c%8].
+//   patch_crop_kernel      image.cropImgPatches (utils/image.py:92-183; pyramidRate = 1 as earlyRejection.py:50 calls it:
+//                          a 64x64 window of nearest-clamped pixels around the truncated cube-centre projection)
+//                          + image.preprocess_patches (utils/image.py:9-36): RGB -> BGR, - mean_BGR, (h,w,c) -> (c,h,w)
+//   nchw_to_p0_kernel      the same network input from host-preprocessed (n,3,64,64) float32 patches
+//   maxpool2d_kernel       Pool2DLayer(2)                                       nets/similarityNet.py:31-47
+//   simil_features_kernel  FlattenLayer(pool5) ++ CropFeatureMapCenterLayer(pool1..4, r=1) -> L2NormLayer
+//                                                                              nets/similarityNet.py:49-57, nets/layers.py:15-81
+//   simil_dense_kernel     DenseLayer(5888 -> 128, linear)                     nets/similarityNet.py:57
+//   pair_simil_kernel      DistanceLayer(Lp=2) + DenseLayer(1, sigmoid)       nets/similarityNet.py:71-77, nets/layers.py:130-138
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "elementwise.h"
+
+namespace sn {
+
+constexpr int kPatch = 64;             // params.__imgPatch_hw_size
+constexpr int kSimilFeat = 5888;       // 512*4 (pool5) + (64 + 128 + 256 + 512) * 4 (centre crops)
+constexpr int kEmb = 128;              // params.__D_imgPatchEmbedding
+
+// One thread = one pixel of one patch. centers: (2, n) float64 = (h, w) projections of the cube centres.
+// patches_u8 (n,64,64,3) RGB and/or p0 (network input, 8-channel group 0: B-mean, G-mean, R-mean, 0...) are written.
+template <int SPLIT>
+__global__ void __launch_bounds__(256) patch_crop_kernel(const uint8_t *img, int H, int W, const double *center_h, const double *center_w,
+                                                         int n, uint8_t *patches_u8, _Float16 *p0, long long lo_off, float mb, float mg, float mr)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)n * kPatch * kPatch) return;
+    const int pw = (int)(idx % kPatch), ph = (int)((idx / kPatch) % kPatch), i = (int)(idx / (kPatch * kPatch));
+    // (center * 1.0).astype(np.int) - patchSize/2, then clip to the image (image.py:160-169)
+    const long long h0 = (long long)center_h[i] - kPatch / 2, w0 = (long long)center_w[i] - kPatch / 2;
+    long long h = h0 + ph, w = w0 + pw;
+    h = h < 0 ? 0 : (h > H - 1 ? H - 1 : h);
+    w = w < 0 ? 0 : (w > W - 1 ? W - 1 : w);
+    const uint8_t *px = img + ((size_t)h * W + (size_t)w) * 3;
+    const uint8_t r = px[0], g = px[1], b = px[2];
+    if (patches_u8) {
+        uint8_t *o = patches_u8 + (size_t)idx * 3;
+        o[0] = r; o[1] = g; o[2] = b;
+    }
+    if (p0) {
+        const float v[8] = {(float)b - mb, (float)g - mg, (float)r - mr, 0.f, 0.f, 0.f, 0.f, 0.f};
+        sn_store8<SPLIT>(p0 + (size_t)idx * 8, lo_off, v);
+    }
+}
+
+template <int SPLIT>
+__global__ void __launch_bounds__(256) nchw_to_p0_kernel(const float *X, int n, _Float16 *p0, long long lo_off)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int hw = kPatch * kPatch;
+    if (idx >= (long long)n * hw) return;
+    const int pix = (int)(idx % hw), i = (int)(idx / hw);
+    const float *s = X + (size_t)i * 3 * hw + pix;
+    const float v[8] = {s[0], s[hw], s[2 * hw], 0.f, 0.f, 0.f, 0.f, 0.f};
+    sn_store8<SPLIT>(p0 + (size_t)idx * 8, lo_off, v);
+}
+
+// in [C/8][N][H][H][8] -> out [C/8][N][H/2][H/2][8]
+template <int SPLIT>
+__global__ void __launch_bounds__(256) maxpool2d_kernel(const _Float16 *in, _Float16 *out, int H, long long total, long long in_lo_off,
+                                                        long long out_lo_off)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int Ho = H >> 1;
+    const int w = (int)(idx % Ho), h = (int)((idx / Ho) % Ho);
+    const long long plane = idx / ((long long)Ho * Ho);          // (c8 * N + n)
+    const _Float16 *p = in + ((plane * H + 2 * h) * H + 2 * w) * 8;
+    float m[8], q[8];
+    sn_load8<SPLIT>(p, in_lo_off, m);
+#pragma unroll
+    for (int o = 1; o < 4; ++o) {
+        sn_load8<SPLIT>(p + ((long long)(o >> 1) * H + (o & 1)) * 8, in_lo_off, q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = q[e] > m[e] ? q[e] : m[e];
+    }
+    sn_store8<SPLIT>(out + idx * 8, out_lo_off, m);
+}
+
+struct SimilFeatArgs {
+    const _Float16 *pool[5];     // pool1..pool5, [C/8][N][H][H][8]
+    long long lo_off[5];
+    float *feat;                 // (N, 5888) L2-normalised
+    int n;
+};
+
+// One workgroup (256 threads) per patch: gather the 5888 features (fp32 = hi + lo), sum of squares, scale.
+template <int SPLIT>
+__global__ void __launch_bounds__(256) simil_features_kernel(SimilFeatArgs a)
+{
+    __shared__ float f[kSimilFeat];
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    // concat order (similarityNet.py:49-55): pool5 flatten, then centre crops of pool1, pool2, pool3, pool4; each (c, h, w)
+    const int src[5] = {4, 0, 1, 2, 3};
+    const int C[5] = {64, 128, 256, 512, 512}, Hs[5] = {32, 16, 8, 4, 2};
+    int base = 0;
+    float ss = 0.f;
+    for (int k = 0; k < 5; ++k) {
+        const int s = src[k], H = Hs[s], c8n = C[s] >> 3, h0 = H / 2 - 1;     // r = 1: rows/cols [H/2-1, H/2+1)
+        // work item = (8-channel group, one of the 4 pixels)
+        for (int t = tid; t < c8n * 4; t += 256) {
+            const int c8 = t >> 2, hh = (t >> 1) & 1, ww = t & 1;
+            float v[8];
+            sn_load8<SPLIT>(a.pool[s] + ((((long long)c8 * a.n + i) * H + (h0 + hh)) * H + (h0 + ww)) * 8, a.lo_off[s], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f[base + ((c8 * 8 + e) << 2) + hh * 2 + ww] = v[e];
+                ss += v[e] * v[e];
+            }
+        }
+        base += C[s] * 4;
+    }
+    for (int o = 32; o; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf(red[0] + red[1] + red[2] + red[3]);
+    for (int t = tid; t < kSimilFeat; t += 256) a.feat[(size_t)i * kSimilFeat + t] = f[t] * inv;
+}
+
+// emb (N,128) = feat (N,5888) . W (5888,128) + b; one workgroup = 8 patches x 128 outputs (W is read once per 8 patches)
+__global__ void __launch_bounds__(128) simil_dense_kernel(const float *feat, const float *W, const float *b, float *emb, int n)
+{
+    __shared__ float fs[8][256];
+    const int j = threadIdx.x, i0 = blockIdx.x * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < kSimilFeat; k0 += 256) {
+        for (int t = j; t < 8 * 256; t += 128) {
+            const int r = t >> 8, k = t & 255;
+            fs[r][k] = (i0 + r < n) ? feat[(size_t)(i0 + r) * kSimilFeat + k0 + k] : 0.f;
+        }
+        __syncthreads();
+        for (int k = 0; k < 256; ++k) {
+            const float w = W[(size_t)(k0 + k) * kEmb + j];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = fmaf(fs[r][k], w, acc[r]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (i0 + r < n) emb[(size_t)(i0 + r) * kEmb + j] = acc[r] + b[j];
+}
+
+// emb_pairs (2*n, 128): rows 2i, 2i+1 form pair i -> simil (n,) = sigmoid(w * ||e1 - e2||_2 + b)
+__global__ void __launch_bounds__(256) pair_simil_kernel(const float *emb_pairs, float *simil, int n, float w, float b)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float *e1 = emb_pairs + (size_t)(2 * i) * kEmb, *e2 = e1 + kEmb;
+    float ss = 0.f;
+    for (int k = lane; k < kEmb; k += 64) { const float d = fabsf(e1[k] - e2[k]); ss += d * d; }
+    for (int o = 32; o; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) simil[i] = 1.0f / (1.0f + expf(-(w * sqrtf(ss) + b)));
+}
+
+}  // namespace sn

@@ -1,0 +1,70 @@
+"""Drop-in for the reference's `utils/earlyRejection.py` (call sites main_reconstruct.py:84-97).
+
+    patch2embedding        utils/earlyRejection.py:6-56    crop patches per view -> preprocess -> similarityNet embedding
+    embeddingPairs2simil   utils/earlyRejection.py:59-90   pair dissimilarity for every 2-combination of views
+    selectFromSimilarity   utils/earlyRejection.py:92-103  bool mask of the cubes worth reconstructing
+
+Same signatures and return values. With the GPU-backed `patch2embedding_fn` of surfacenet_amd.similarityNet the
+crop + preprocess + network chain of a view runs without the patches ever leaving HBM (sn_crop_embed); with any other
+callable the reference's three-step protocol is followed literally.
+"""
+import numpy as np
+
+from . import image, runtime
+from .viewPairSelection import k_combination_np, yield_batch_npBool
+
+
+def patch2embedding(images_list, img_h_cubesCorner, img_w_cubesCorner, patch2embedding_fn, patches_mean_bgr, N_cubes, N_views, D_embedding,
+                    patchSize, batchSize, cubeCenter_hw):
+    """-> patches_embedding (N_cubes, N_views, D_embedding) float32, inScope_cubes_vs_views (N_cubes, N_views) bool.
+    Out-of-scope (cube, view) entries keep the embedding of an all-black patch (utils/earlyRejection.py:31-34)."""
+    inScope_cubes_vs_views = np.zeros((N_cubes, N_views), dtype=bool)
+    patch_allBlack = image.preprocess_patches(np.zeros((1, patchSize, patchSize, 3), dtype=np.float32), mean_BGR=patches_mean_bgr)
+    patches_embedding = np.zeros((N_cubes, N_views, D_embedding), dtype=np.float32)
+    patches_embedding[:, :] = patch2embedding_fn(np.ascontiguousarray(patch_allBlack))[0]
+    fused = bool(getattr(patch2embedding_fn, "sn_gpu", False)) and patchSize == 64
+    if fused:
+        ctx = runtime.any_context()
+        runtime.bind_images(ctx, images_list)
+    proj_h = np.stack([img_h_cubesCorner.min(axis=-1), img_h_cubesCorner.max(axis=-1)], axis=-1)
+    proj_w = np.stack([img_w_cubesCorner.min(axis=-1), img_w_cubesCorner.max(axis=-1)], axis=-1)
+    for _view, _image in enumerate(images_list):
+        _inScope = image.img_hw_cubesCorner_inScopeCheck(hw_shape=_image.shape[:2], img_h_cubesCorner=img_h_cubesCorner[_view],
+                                                         img_w_cubesCorner=img_w_cubesCorner[_view])
+        inScope_cubes_vs_views[:, _view] = _inScope
+        n_in = int(_inScope.sum())
+        if not n_in:
+            continue
+        centers = cubeCenter_hw[:, _view, _inScope]
+        if fused:
+            emb = ctx.crop_embed(_view, centers[0], centers[1], patches_mean_bgr)
+        else:
+            patches = image.cropImgPatches(img=_image, range_h=proj_h[_view][_inScope], range_w=proj_w[_view][_inScope], patchSize=patchSize,
+                                           pyramidRate=1, interp_order=2, cubeCenter_hw=centers)
+            pre = np.ascontiguousarray(image.preprocess_patches(patches.astype(np.float32), mean_BGR=patches_mean_bgr))
+            emb = np.zeros((n_in, D_embedding), dtype=np.float32)
+            for _batch in yield_batch_npBool(N_all=n_in, batch_size=batchSize):
+                emb[_batch] = patch2embedding_fn(pre[_batch])
+        patches_embedding[_inScope, _view] = emb
+    return patches_embedding, inScope_cubes_vs_views
+
+
+def embeddingPairs2simil(embeddings, N_views, inScope_cubes_vs_views, embeddingPair2simil_fn, batchSize, viewPairs):
+    """embeddings (N_cubes, N_views, D) -> dissimilarity (N_cubes, N_viewPairs) over all 2-combinations of range(N_views)
+    (the `viewPairs` argument is recomputed, as in the reference: utils/earlyRejection.py:74)."""
+    viewPairs = k_combination_np(range(N_views), k=2)
+    N_viewPairs, N_cubes = viewPairs.shape[0], embeddings.shape[0]
+    # rows (cube i, view j) in cube-major, pair-major, (first, second) order == the reference's yield_batch_ij_npBool walk
+    ii = np.repeat(np.arange(N_cubes), 2 * N_viewPairs)
+    jj = np.tile(viewPairs.flatten(), N_cubes)
+    step = int(batchSize * 2)
+    out = []
+    for a in range(0, ii.size, step):
+        out.append(embeddingPair2simil_fn(np.ascontiguousarray(embeddings[ii[a:a + step], jj[a:a + step]])))
+    return np.vstack(out).reshape((N_cubes, N_viewPairs))
+
+
+def selectFromSimilarity(dissimilarityProb, N_viewPairs4inference):
+    """(N_cubes,) bool: at least N_viewPairs4inference pairs with 0.1 < dissimilarity < 0.5 (utils/earlyRejection.py:92-103)."""
+    similarityBool = (dissimilarityProb < 0.5) & (dissimilarityProb > 0.1)
+    return (similarityBool.sum(axis=1) >= N_viewPairs4inference).astype(bool)

@@ -130,6 +130,10 @@ def synthetic_param_values(seed=0, with_relative_weight_net=True):
 def to_blob(values):
     """-> (blob float32 1-D, (ParamDesc * n) array) for sn_load_weights."""
     validate(values)
+    return _pack_blob(values)
+
+
+def _pack_blob(values):
     descs = (_lib.ParamDesc * len(values))()
     chunks, off = [], 0
     for i, v in enumerate(values):
@@ -141,3 +145,52 @@ def to_blob(values):
         chunks.append(v.ravel())
         off += v.size
     return np.concatenate(chunks), descs
+
+
+# ---- similarityNet (nets/similarityNet.py:23-77): 13 x (W (Cout,Cin,3,3), b), embedding W (5888,128), b, similarity W (1,1), b ----
+SIMIL_CONVS = [("conv1_1", 3, 64), ("conv1_2", 64, 64), ("conv2_1", 64, 128), ("conv2_2", 128, 128), ("conv3_1", 128, 256),
+               ("conv3_2", 256, 256), ("conv3_3", 256, 256), ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3", 512, 512),
+               ("conv5_1", 512, 512), ("conv5_2", 512, 512), ("conv5_3", 512, 512)]
+D_SIMIL_FEATURE = 512 * 4 + (64 + 128 + 256 + 512) * 4     # pool5 flattened + 2x2 centre crops of pool1..4 = 5888
+D_EMBEDDING = 128                                           # params.py:88
+SIMIL_PARAM_SHAPES = [sh for _, ci, co in SIMIL_CONVS for sh in ((co, ci, 3, 3), (co,))] + \
+    [(D_SIMIL_FEATURE, D_EMBEDDING), (D_EMBEDDING,), (1, 1), (1,)]
+
+
+def validate_simil(values):
+    if len(values) != len(SIMIL_PARAM_SHAPES):
+        raise ValueError("similarityNet weight file must hold %d arrays, got %d" % (len(SIMIL_PARAM_SHAPES), len(values)))
+    for i, (v, sh) in enumerate(zip(values, SIMIL_PARAM_SHAPES)):
+        if tuple(np.shape(v)) != sh:
+            raise ValueError("similarityNet param %d: expected shape %s, got %s" % (i, sh, np.shape(v)))
+
+
+def load_simil_pickle(path):
+    """The reference's similarityNet `*.model` file (nets/similarityNet.py:240-242): py2 pickle of a flat list of arrays."""
+    with open(path, "rb") as f:
+        values = pickle.load(f, encoding="latin1")
+    values = [np.asarray(v, dtype=np.float32) for v in values]
+    validate_simil(values)
+    return values
+
+
+def synthetic_simil_param_values(seed=0):
+    """Seeded He-style weights: activations stay O(1) from conv1_1 on (inputs are pixel - mean, rms ~75), embeddings are
+    O(0.3) per component and the pair similarity is not saturated. Stand-in for the unavailable trained model."""
+    rs = np.random.RandomState(1000 + seed)
+    values = []
+    for i, (_, ci, co) in enumerate(SIMIL_CONVS):
+        bound = np.sqrt(6.0 / (ci * 9)) / (75.0 if i == 0 else 1.0)
+        values.append(rs.uniform(-bound, bound, size=(co, ci, 3, 3)).astype(np.float32))
+        values.append(rs.uniform(-0.1, 0.1, size=(co,)).astype(np.float32))
+    bound = 25.0 * np.sqrt(3.0 / D_SIMIL_FEATURE)
+    values.append(rs.uniform(-bound, bound, size=(D_SIMIL_FEATURE, D_EMBEDDING)).astype(np.float32))
+    values.append(rs.uniform(-0.1, 0.1, size=(D_EMBEDDING,)).astype(np.float32))
+    values.append(np.asarray([[rs.uniform(0.5, 1.5)]], dtype=np.float32))
+    values.append(np.asarray([rs.uniform(-2.0, -1.0)], dtype=np.float32))
+    return values
+
+
+def simil_to_blob(values):
+    validate_simil(values)
+    return _pack_blob(values)

@@ -42,3 +42,18 @@ def synthetic_scene(n, n_vp=2, s=32, seed=0, hw=(1200, 1600)):
     pairs = np.stack([pair_opts[(np.arange(n_vp) + i) % 4] for i in range(n)]).astype(np.int64)
     w = (np.random.RandomState(seed + 1).rand(n, n_vp) + 0.1).astype(np.float32)
     return dict(cams=cams, imgs=imgs, xyz=xyz, resol=resol, pairs=pairs, w=w)
+
+
+# Exactly-rounded stand-ins for the two network callables of utils/earlyRejection.py, used when the reference's host
+# logic was recorded (oracle/gen_golden_simil.py) and when it is replayed (tests/test_oracle_simil.py): float64 sums of
+# float32 values spanning < 2^29 are exact in any order, fsum is exactly rounded, IEEE division is correctly rounded.
+def toy_embedding(patches):
+    x = np.asarray(patches, dtype=np.float64).reshape(patches.shape[0], 128, -1)      # (n, 128, 96)
+    return (x.sum(axis=2) / 1000.0).astype(np.float32)
+
+
+def toy_pair_simil(emb_pairs):
+    import math
+    e = np.asarray(emb_pairs, dtype=np.float64).reshape(-1, 2, emb_pairs.shape[-1])
+    d = np.asarray([math.fsum(np.abs(a - b)) for a, b in e])
+    return (d / (d + 300.0)).astype(np.float32)[:, None]
