@@ -120,6 +120,45 @@ def post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, steps, keep_frac=0.1):
     return out
 
 
+def simil_net(surfacenet_amd, ctx, scene, steps, n=2048):
+    """Extra, non-headline measurement: earlyRejection.patch2embedding's inner loop for one view --
+    crop n 64x64 patches around projected cube centres, preprocess, similarityNet embedding -- without leaving HBM
+    (sn_crop_embed); embeddings (n,128) copied to the host every step."""
+    from surfacenet_amd import weights
+    from oracle import simil_oracle
+    values = weights.synthetic_simil_param_values(0)
+    ctx.load_simil_param_values(values)
+    mean = np.asarray([103.939, 116.779, 123.68], dtype=np.float32)           # params.py:130
+    rs = np.random.RandomState(1)
+    H, W = scene["imgs"][0].shape[:2]
+    ch, cw = rs.uniform(0, H, n), rs.uniform(0, W, n)
+    ctx.crop_embed(0, ch, cw, mean)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        emb = ctx.crop_embed(0, ch, cw, mean)
+    dt = (time.perf_counter() - t0) / steps
+    prof = ctx.profile(); ctx.profile_enable(False); ctx.profile_reset()
+    flops_patch = sum(2.0 * (64 >> st) ** 2 * 9 * ci * co for (_, ci, co), st in zip(weights.SIMIL_CONVS, [0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4]))
+    conv = {k: v for k, v in prof.items() if k.startswith("s_conv")}
+    conv_ms = sum(v["ms"] for v in conv.values()) / steps
+    dom = max(conv, key=lambda k: conv[k]["ms"])
+    d = conv[dom]
+    raw = simil_oracle.crop_patches(scene["imgs"][0], ch[:4], cw[:4])
+    X = simil_oracle.preprocess(raw, mean)
+    simil_oracle.embedding_torch(X[:1], values, dtype="float32")
+    t0 = time.perf_counter()
+    ref = simil_oracle.embedding_torch(X, values, dtype="float32")
+    t_cpu = (time.perf_counter() - t0) / 4
+    return {"value": round(n / dt, 1), "unit": "patches/s", "what": "crop + preprocess + similarityNet embedding, %d patches of one view per step, embeddings to host" % n,
+            "ms_per_step": round(dt * 1e3, 3), "gflop_per_patch": round(flops_patch / 1e9, 3),
+            "convs_tflops": round(flops_patch * n / (conv_ms * 1e-3) / 1e12, 1), "convs_ms_per_step": round(conv_ms, 3),
+            "dominant": {"kernel": "conv3d_f16_mfma<K2D %s>" % dom, "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                         "achieved_tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1), "frac_of_f16_mfma_peak": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4)},
+            "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if v["launches"]},
+            "cpu_oracle_patches_per_s": round(1.0 / t_cpu, 2), "check_Linf_vs_oracle_f32": float(np.abs(emb[:4] - ref).max())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +171,7 @@ def main():
                     help="f16x3 (default): hi/lo split fp16 operands, fp32-class results (parity grade); f16: fast mode, L_inf ~2e-3")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16 fast-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-simil", action="store_true", help="skip the extra similarityNet (early rejection) measurement")
     ap.add_argument("--no-post-pass", action="store_true", help="skip the extra whole-loop-body (ray pooling / dense2sparse) measurement")
     args = ap.parse_args()
 
@@ -254,6 +294,8 @@ def main():
             out["fast_mode_f16"] = fast_mode(surfacenet_amd, scene, values, s, n, n_vp, local_rank, max(3, args.steps // 2))
         if world == 1 and not args.no_post_pass:
             out["loop_body_with_post_pass"] = post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, max(3, args.steps // 2))
+        if world == 1 and not args.no_simil:
+            out["similarity_net"] = simil_net(surfacenet_amd, ctx, scene, max(2, args.steps // 3))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, values, s, n_vp)
         print(json.dumps(out))

@@ -164,7 +164,8 @@ struct ConvCfg {
     static constexpr int XS = MF / 4;                      // x-slices per wave
     static constexpr int NW = NW_;                         // waves per workgroup
     static constexpr int NT = NW * 64;
-    static constexpr int TX = NW * XS, TY = 8, TZ = 8;
+    static constexpr bool F4 = (K2D == 2);                 // 2-D maps of 4x4 pixels: one MFMA voxel fragment = one whole 4x4 image
+    static constexpr int TX = F4 ? NW * MF : NW * XS, TY = F4 ? 4 : 8, TZ = F4 ? 4 : 8;
     static constexpr int HX = TX + 2 * RX, HY = TY + 2 * R, HZ = TZ + 2 * R;
     static constexpr int HVOX = HX * HY * HZ;
     static constexpr int CS8MAX = CS8;                     // 8-channel groups per slab
@@ -306,7 +307,7 @@ conv3d_f16_mfma(ConvArgs a)
     int xbase[MF];
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-        const int hx = wave * C::XS + (m >> 2), hy = 2 * (m & 3) + (v >> 3), hz = v & 7;
+        const int hx = C::F4 ? wave * MF + m : wave * C::XS + (m >> 2), hy = C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3), hz = C::F4 ? (v & 3) : (v & 7);
         xbase[m] = ((hx * C::HY + hy) * C::HZ + hz) * C::VS;
     }
     const unsigned xbuf_a = lds_addr(xbuf), wbuf_a = lds_addr(wbuf) + lane * 16, kbuf_a = lds_addr(kbuf) + kq * 4;
@@ -530,7 +531,7 @@ conv3d_f16_mfma(ConvArgs a)
         } else if constexpr (EPI == EPI_STORE) {
 #pragma unroll
             for (int m = 0; m < MF; ++m) {
-                const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
+                const int gx = x0 + (C::F4 ? wave * MF + m : wave * C::XS + (m >> 2)), gy = y0 + (C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3)), gz = z0 + (C::F4 ? (v & 3) : (v & 7));
                 const bool valid = gx < DX && gy < D && gz < D;
                 const size_t vlin = ((size_t)gx * D + gy) * D + gz;
 #pragma unroll
@@ -582,7 +583,7 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
                 }
-                const int gx = x0 + wave * C::XS + (m >> 2), gy = y0 + 2 * (m & 3) + (v >> 3), gz = z0 + (v & 7);
+                const int gx = x0 + (C::F4 ? wave * MF + m : wave * C::XS + (m >> 2)), gy = y0 + (C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3)), gz = z0 + (C::F4 ? (v & 3) : (v & 7));
                 const bool valid = gx < DX && gy < D && gz < D;
                 const size_t vox = ((size_t)(b * DX + gx) * D + gy) * D + gz;
                 p += __shfl_xor(p, 16);

@@ -123,28 +123,55 @@ __global__ void __launch_bounds__(256) simil_features_kernel(SimilFeatArgs a)
     for (int t = tid; t < kSimilFeat; t += 256) a.feat[(size_t)i * kSimilFeat + t] = f[t] * inv;
 }
 
-// emb (N,128) = feat (N,5888) . W (5888,128) + b; one workgroup = 8 patches x 128 outputs (W is read once per 8 patches)
-__global__ void __launch_bounds__(128) simil_dense_kernel(const float *feat, const float *W, const float *b, float *emb, int n)
+// emb (N,128) = feat (N,5888) . W (5888,128) + b in fp32. One workgroup (256 threads) = 32 patches x 128 outputs x one of
+// kDenseKS K-ranges (blockIdx.y), thread tile 4 patches x 4 outputs, K staged through LDS in steps of 32. Partial sums go to
+// part[ks][n][128]; simil_dense_reduce_kernel adds them in fixed order (+ bias): deterministic, and independent of the batch
+// size and of the patch's position in the batch.
+constexpr int kDenseKS = 8, kDenseKR = kSimilFeat / kDenseKS;      // 736 = 23 steps of 32
+__global__ void __launch_bounds__(256) simil_dense_kernel(const float *feat, const float *W, float *part, int n)
 {
-    __shared__ float fs[8][256];
-    const int j = threadIdx.x, i0 = blockIdx.x * 8;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < kSimilFeat; k0 += 256) {
-        for (int t = j; t < 8 * 256; t += 128) {
-            const int r = t >> 8, k = t & 255;
-            fs[r][k] = (i0 + r < n) ? feat[(size_t)(i0 + r) * kSimilFeat + k0 + k] : 0.f;
+    constexpr int TM = 32, TK = 32;
+    __shared__ float As[TK][TM + 1];
+    __shared__ __attribute__((aligned(16))) float Ws[TK][kEmb];
+    const int tid = threadIdx.x, i0 = blockIdx.x * TM;
+    const int tj = (tid & 31) * 4, ti = (tid >> 5) * 4;          // outputs tj..tj+3, patches ti..ti+3
+    float acc[4][4] = {};
+    const int kbeg = blockIdx.y * kDenseKR;
+    for (int k0 = kbeg; k0 < kbeg + kDenseKR; k0 += TK) {
+        for (int t = tid; t < TM * TK; t += 256) {
+            const int r = t / TK, k = t - r * TK;
+            As[k][r] = (i0 + r < n) ? feat[(size_t)(i0 + r) * kSimilFeat + k0 + k] : 0.f;
+        }
+        for (int t = tid; t < TK * kEmb / 4; t += 256) {
+            const int k = t / (kEmb / 4), c4 = t - k * (kEmb / 4);
+            *reinterpret_cast<float4 *>(&Ws[k][c4 * 4]) = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + k) * kEmb + c4 * 4);
         }
         __syncthreads();
-        for (int k = 0; k < 256; ++k) {
-            const float w = W[(size_t)(k0 + k) * kEmb + j];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] = fmaf(fs[r][k], w, acc[r]);
+#pragma unroll 8
+        for (int k = 0; k < TK; ++k) {
+            const float4 w = *reinterpret_cast<const float4 *>(&Ws[k][tj]);
+            const float a0 = As[k][ti], a1 = As[k][ti + 1], a2 = As[k][ti + 2], a3 = As[k][ti + 3];
+            acc[0][0] = fmaf(a0, w.x, acc[0][0]); acc[0][1] = fmaf(a0, w.y, acc[0][1]); acc[0][2] = fmaf(a0, w.z, acc[0][2]); acc[0][3] = fmaf(a0, w.w, acc[0][3]);
+            acc[1][0] = fmaf(a1, w.x, acc[1][0]); acc[1][1] = fmaf(a1, w.y, acc[1][1]); acc[1][2] = fmaf(a1, w.z, acc[1][2]); acc[1][3] = fmaf(a1, w.w, acc[1][3]);
+            acc[2][0] = fmaf(a2, w.x, acc[2][0]); acc[2][1] = fmaf(a2, w.y, acc[2][1]); acc[2][2] = fmaf(a2, w.z, acc[2][2]); acc[2][3] = fmaf(a2, w.w, acc[2][3]);
+            acc[3][0] = fmaf(a3, w.x, acc[3][0]); acc[3][1] = fmaf(a3, w.y, acc[3][1]); acc[3][2] = fmaf(a3, w.z, acc[3][2]); acc[3][3] = fmaf(a3, w.w, acc[3][3]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-        if (i0 + r < n) emb[(size_t)(i0 + r) * kEmb + j] = acc[r] + b[j];
+    for (int r = 0; r < 4; ++r)
+        if (i0 + ti + r < n)
+            *reinterpret_cast<float4 *>(part + ((size_t)blockIdx.y * n + i0 + ti + r) * kEmb + tj) = float4{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+}
+
+__global__ void __launch_bounds__(256) simil_dense_reduce_kernel(const float *part, const float *b, float *emb, int n)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * kEmb) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kDenseKS; ++ks) acc += part[(size_t)ks * n * kEmb + idx];
+    emb[idx] = acc + b[idx & (kEmb - 1)];
 }
 
 // emb_pairs (2*n, 128): rows 2i, 2i+1 form pair i -> simil (n,) = sigmoid(w * ||e1 - e2||_2 + b)

@@ -364,7 +364,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
 {
     using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV, K2D>;
     if (DX <= 0) DX = D;
-    if (L.k2d != K2D) return fail(SN_ERR_STATE, "%s: packed for a different tap geometry", L.name.c_str());
+    if ((L.k2d != 0) != (K2D != 0)) return fail(SN_ERR_STATE, "%s: packed for a different tap geometry", L.name.c_str());
     if (L.nf != NF || L.ks != KS || L.dil != DIL || L.cs8max != C::CS8MAX || L.split != SPLIT)
         return fail(SN_ERR_STATE, "%s: packed for a different kernel configuration", L.name.c_str());
     ConvArgs a;
@@ -1194,8 +1194,11 @@ static const int kSimC[14] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512,
 static const int kSimStage[13] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4};                          // H = 64 >> stage
 static const char *const kSimName[13] = {"s_conv1_1", "s_conv1_2", "s_conv2_1", "s_conv2_2", "s_conv3_1", "s_conv3_2", "s_conv3_3",
                                          "s_conv4_1", "s_conv4_2", "s_conv4_3", "s_conv5_1", "s_conv5_2", "s_conv5_3"};
-static constexpr int kSimParams = 30, kSimChunk = 512, kSimNF = 4, kSimCS8 = 2;
+static constexpr int kSimParams = 30, kSimChunk = 2048, kSimNF = 4, kSimCS8 = 2;
 #define SCONV 3, 1, 4, kSimNF, EPI_STORE, SP, kSimCS8, 2, 8, 0, 1
+// the 4x4 maps of conv5_x: one MFMA voxel fragment = one image (K2D = 2), 16 images x 128 output channels per workgroup
+#define SCONV5 3, 1, 2, 8, EPI_STORE, SP, kSimCS8, 2, 8, 0, 2
+static int simil_nf(int i) { return kSimStage[i] == 4 ? 8 : kSimNF; }
 
 static int simil_mode(sn_ctx *c) { return c->split == 0 ? 0 : 1; }   // f16m8 contexts run this net in f16x3 (own workspace)
 
@@ -1212,7 +1215,7 @@ static int simil_pack(sn_ctx *c)
         L.name = kSimName[i]; L.cin = kSimC[i]; L.cout = kSimC[i + 1]; L.ks = 3; L.dil = 1; L.act = 0; L.k2d = 1;
         const float *W = c->simil_host.data() + c->simil_descs[2 * i].offset, *b = c->simil_host.data() + c->simil_descs[2 * i + 1].offset;
         std::vector<float> one((size_t)L.cout, 1.f), zero((size_t)L.cout, 0.f);
-        if ((rc = pack_conv(c, L, W, b, one.data(), zero.data(), one.data(), kSimNF, L.cout / (16 * kSimNF), kSimCS8, want)) != SN_OK) return rc;
+        if ((rc = pack_conv(c, L, W, b, one.data(), zero.data(), one.data(), simil_nf(i), L.cout / (16 * simil_nf(i)), kSimCS8, want)) != SN_OK) return rc;
     }
     c->simil_split = want;
     return SN_OK;
@@ -1249,7 +1252,7 @@ extern "C" int sn_simil_load_weights(sn_ctx *c, const float *blob, size_t n_floa
 // Workspace of one chunk: every tensor [C/8][cap][H][H][8] fp16 (+ second plane right behind), carved from one allocation.
 struct SimilWs {
     Act p0, a[5][2], pool[5];
-    float *feat, *emb; double *centers; unsigned char *patches;
+    float *feat, *emb, *part; double *centers; unsigned char *patches;
 };
 static size_t simil_carve(sn_ctx *c, int cap, int npl, SimilWs *w)
 {
@@ -1272,6 +1275,7 @@ static size_t simil_carve(sn_ctx *c, int cap, int npl, SimilWs *w)
     auto raw = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
     t.feat = reinterpret_cast<float *>(raw((size_t)cap * kSimilFeat * 4));
     t.emb = reinterpret_cast<float *>(raw((size_t)cap * kEmb * 4));
+    t.part = reinterpret_cast<float *>(raw((size_t)cap * kEmb * 4 * kDenseKS));
     t.centers = reinterpret_cast<double *>(raw((size_t)cap * 2 * 8));
     t.patches = reinterpret_cast<unsigned char *>(raw((size_t)cap * kPatch * kPatch * 3));
     if (w) *w = t;
@@ -1307,7 +1311,9 @@ static int run_simil_t(sn_ctx *c, const SimilWs &w, int n)
         const bool last = (i == 12 || kSimStage[i + 1] != st);
         Act out = w.a[st][flip[st]];
         flip[st] ^= 1;
-        if ((rc = launch_conv<SCONV>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n)) != SN_OK) return rc;
+        rc = st == 4 ? launch_conv<SCONV5>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n)
+                     : launch_conv<SCONV>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
+        if (rc != SN_OK) return rc;
         cur = out; cur_cs = kSimC[i + 1];
         if (last) {
             const long long total = (long long)(cur_cs / 8) * n * (H / 2) * (H / 2);
@@ -1328,7 +1334,8 @@ static int run_simil_t(sn_ctx *c, const SimilWs &w, int n)
     }
     {
         ProfScope ps(c, "s_dense", 2.0 * n * kSimilFeat * kEmb, (double)n * (kSimilFeat + kEmb) * 4.0 + (double)kSimilFeat * kEmb * 4.0);
-        hipLaunchKernelGGL(simil_dense_kernel, dim3((unsigned)((n + 7) / 8)), dim3(128), 0, c->stream, w.feat, c->semb_W, c->semb_b, w.emb, n);
+        hipLaunchKernelGGL(simil_dense_kernel, dim3((unsigned)((n + 31) / 32), kDenseKS), dim3(256), 0, c->stream, w.feat, c->semb_W, w.part, n);
+        hipLaunchKernelGGL(simil_dense_reduce_kernel, dim3((unsigned)((n * kEmb + 255) / 256)), dim3(256), 0, c->stream, w.part, c->semb_b, w.emb, n);
         HIPCHK(hipGetLastError());
     }
     return SN_OK;

@@ -63,11 +63,11 @@ def test_patch2embedding_vs_oracle(sn, precision, n):
 
 
 def test_patch2embedding_chunking_and_precision_switch(sn):
-    """More patches than one workspace chunk (512) and a precision switch in between: identical rows per patch."""
+    """More patches than one workspace chunk (2048) and a precision switch in between: identical rows per patch."""
     from surfacenet_amd import weights
     values = weights.synthetic_simil_param_values(2)
     base = simil_oracle.preprocess(np.random.RandomState(5).randint(0, 256, (6, 64, 64, 3)).astype(np.uint8), MEAN_BGR)
-    X = np.ascontiguousarray(np.tile(base, (100, 1, 1, 1))[:515])
+    X = np.ascontiguousarray(np.tile(base, (342, 1, 1, 1))[:2051])
     with sn.Context(cube_D=8, max_samples=2) as ctx:
         ctx.load_simil_param_values(values)
         a = ctx.patch2embedding(X)
@@ -76,7 +76,7 @@ def test_patch2embedding_chunking_and_precision_switch(sn):
         b = ctx.patch2embedding(base)
         assert lib.sn_set_precision(ctx._h, 1) == 0               # back to f16x3: weights are re-packed
         c = ctx.patch2embedding(base)
-    assert np.array_equal(a[:6], c) and np.array_equal(a[6:12], c) and np.array_equal(a[510:515], c[:5])
+    assert np.array_equal(a[:6], c) and np.array_equal(a[6:12], c) and np.array_equal(a[2046:2051], c[:5])
     assert np.abs(b - c).max() < TOL_EMB_F16 and not np.array_equal(b, c)
 
 
