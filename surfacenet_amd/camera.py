@@ -1,6 +1,7 @@
 """Host-side projection helpers of the reference's `utils/camera.py` that feed early rejection:
 O(N_views * N_cubes * 8) float64 arithmetic, kept in numpy with the reference's exact operation order.
 
+    cameraPs2Ts                  utils/camera.py:87-120   (camera centres by cofactors, as the reference computes them)
     perspectiveProj              utils/camera.py:123-184
     perspectiveProj_cubesCorner  utils/camera.py:188-245
 (`viewPairAngles_wrt_pts` lives in surfacenet_amd/viewPairSelection.py.)
@@ -42,3 +43,14 @@ def perspectiveProj_cubesCorner(projection_M, cube_xyz_min, cube_D_mm, return_in
     corners = cube_xyz_min[:, None, :] + shift
     img_h, img_w = perspectiveProj(projection_M, corners.reshape((N_pts * 8, 3)), return_int_hw=return_int_hw, return_depth=False)
     return img_h.reshape((-1, N_pts, 8)), img_w.reshape((-1, N_pts, 8))
+
+
+def cameraPs2Ts(cameraPOs):
+    """Camera centres (N,3) (or a list, if a list is given) of projection matrices (3,4): the null vector of P by
+    cofactor expansion, C_i = (-1)^i det(P without column i), de-homogenised (utils/camera.py:87-120)."""
+    def center(P):
+        P = np.asarray(P)
+        cof = np.array([(-1) ** i * np.linalg.det(P[:, [j for j in range(4) if j != i]]) for i in range(4)])
+        return cof[:3] / cof[3]
+    Ts = [center(P) for P in cameraPOs]
+    return Ts if type(cameraPOs) is list else np.stack(Ts)

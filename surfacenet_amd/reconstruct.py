@@ -7,6 +7,8 @@
 * `SparseLoop`             the WHOLE loop body (main_reconstruct.py:134-160: CVC -> CNN -> fusion -> voxel colours ->
                            ray pooling -> dense2sparse) device-resident: only cube parameters go up and only the packed
                            sparse voxel lists come down
+* `reconstruct_scene`       main_reconstruct.reconstruction() from the early rejection to the sparse voxel lists
+                           (main_reconstruct.py:67-173) for in-memory images / cameras / cubes: every stage on the GPU
 * `gather_sparse_sharded`   the multi-GPU exchange when the post-pass runs on the GPU: every rank holds only the packed
                            sparse voxel lists of its cube shard (9 B per kept voxel instead of 4 B x s^3 per cube); two
                            all-gathers (lengths, then one padded byte buffer) rebuild the global lists on every rank
@@ -202,3 +204,75 @@ def gather_sparse_sharded(local, lo, group=None, device=None):
             if votes is not None:
                 out[4].append(votes[a:e].copy())
     return out[0], out[1], out[2], out[3], out[4], np.concatenate(out[5], axis=0)
+
+
+def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, patch2embedding_fn,
+                      embeddingPair2simil_fn, viewPair_relativeImpt_fn, cube_Dcenter, patches_mean_bgr, batchSize_similNet_patch2embedding=100,
+                      batchSize_similNet_embeddingPair2simil=100000, batchSize_viewPair_w=100000, batchSize_nViewPair_SurfaceNet=None,
+                      weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64, ctx=None):
+    """The body of main_reconstruct.reconstruction() between file input and PLY output (main_reconstruct.py:67-173):
+    corner / centre projections -> early rejection (similarityNet) -> view-pair selection (relative-weight MLP) ->
+    per batch: CVC, SurfaceNet, fusion, voxel colours, ray pooling, dense2sparse -> thinning masks.
+    The three *_fn arguments are the callables of similarityNet.similarityNet_inference / SurfaceNet.SurfaceNet_inference
+    (their weights are bound in `runtime`). Returns a dict with the reference's variable names. Not included (SURVEY §2.1,
+    out of scope): image / camera readers, cube tiling, cross-cube denoising, PLY / npz writers."""
+    from . import camera, earlyRejection, runtime, sparseCubes, viewPairSelection
+    cameraPOs_np = np.asarray(cameraPOs_np, dtype=np.float64)
+    N_vp = int(N_viewPairs4inference)
+    # main_reconstruct.py:67-71
+    img_h_cubesCorner, img_w_cubesCorner = camera.perspectiveProj_cubesCorner(projection_M=cameraPOs_np, cube_xyz_min=cubes_param_np['xyz'],
+                                                                              cube_D_mm=cube_D_mm, return_int_hw=False, return_depth=False)
+    img_h_cubesCenter, img_w_cubesCenter = camera.perspectiveProj(projection_M=cameraPOs_np, xyz_3D=cubes_param_np['xyz'] + cube_D_mm / 2.,
+                                                                  return_int_hw=False, return_depth=False)
+    N_views, N_cubes = img_h_cubesCorner.shape[:2]
+    cameraTs_np = camera.cameraPs2Ts(cameraPOs=cameraPOs_np)                                    # main_reconstruct.py:50
+    # :84-97 early rejection
+    viewPairs = viewPairSelection.k_combination_np(range(N_views), k=2)
+    patches_embedding, inScope_cubes_vs_views = earlyRejection.patch2embedding(
+        images_list, img_h_cubesCorner, img_w_cubesCorner, patch2embedding_fn, patches_mean_bgr, N_cubes, N_views, D_embedding, patchSize=patchSize,
+        batchSize=batchSize_similNet_patch2embedding, cubeCenter_hw=np.stack([img_h_cubesCenter, img_w_cubesCenter], axis=0))
+    dissimilarity = earlyRejection.embeddingPairs2simil(embeddings=patches_embedding, embeddingPair2simil_fn=embeddingPair2simil_fn,
+                                                        inScope_cubes_vs_views=inScope_cubes_vs_views, viewPairs=viewPairs, N_views=N_views,
+                                                        batchSize=batchSize_similNet_embeddingPair2simil)
+    validCubes = earlyRejection.selectFromSimilarity(dissimilarityProb=dissimilarity, N_viewPairs4inference=N_vp)
+    out = dict(patches_embedding=patches_embedding, inScope_cubes_vs_views=inScope_cubes_vs_views, dissimilarity=dissimilarity, validCubes=validCubes,
+               prediction_list=[], rgb_list=[], vxl_ijk_list=[], rayPooling_votes_list=[], cube_ijk_np=None, param_np=None, viewPair_np=None,
+               vxl_mask_list=[])
+    if not validCubes.any():
+        return out
+    # :103-116 view-pair selection
+    viewPairs4Reconstr, w_viewPairs4Reconstr = viewPairSelection.viewPairSelection(
+        cameraTs_np=cameraTs_np, e_viewPairs=patches_embedding, d_viewPairs=dissimilarity, validCubes=validCubes,
+        cubeCenters_xyz=cubes_param_np['xyz'] + cube_D_mm / 2., viewPair_relativeImpt_fn=viewPair_relativeImpt_fn, batchSize=batchSize_viewPair_w,
+        N_viewPairs4inference=N_vp, viewPairs=viewPairs)
+    if weighted_fusion is False:
+        w_viewPairs4Reconstr[:] = 1.0 / N_vp
+    out.update(viewPairs4Reconstr=viewPairs4Reconstr, w_viewPairs4Reconstr=w_viewPairs4Reconstr)
+    # :126-166 the cube-batch loop, device-resident
+    ctx = ctx or runtime.context_for(cube_D)
+    runtime.bind_scene(ctx, cameraPOs_np, images_list)
+    bs = int(batchSize_nViewPair_SurfaceNet or max(1, ctx.max_samples // N_vp))
+    bs = min(bs, max(1, ctx.max_samples // N_vp))
+    loop = SparseLoop(ctx, N_vp, max_cubes=bs, min_prob=min_prob, rayPool_thresh=0, enable_centerCrop=True, cube_Dcenter=cube_Dcenter,
+                      enable_rayPooling=True)
+    try:
+        for _batch in gen_non0Batch_npBool(validCubes, bs):
+            sel = _batch[validCubes]
+            nonempty, ijk_l, p_l, rgb_l, v_l, xyz_new = loop.run(viewPairs4Reconstr[sel], cubes_param_np['xyz'][_batch], cubes_param_np['resol'][_batch],
+                                                                 w_viewPairs4Reconstr[sel])
+            param_sub = np.copy(cubes_param_np[_batch])
+            param_sub['xyz'] = xyz_new
+            param_sub = param_sub[nonempty]
+            vp_sub = viewPairs4Reconstr[sel].astype(np.uint16)[nonempty]
+            ijk_sub = cubes_param_np['ijk'][_batch][nonempty]
+            out["prediction_list"].extend(p_l); out["rgb_list"].extend(rgb_l); out["vxl_ijk_list"].extend(ijk_l)
+            out["rayPooling_votes_list"].extend(v_l)
+            out["param_np"] = param_sub if out["param_np"] is None else np.concatenate([out["param_np"], param_sub], axis=0)
+            out["viewPair_np"] = vp_sub if out["viewPair_np"] is None else np.vstack([out["viewPair_np"], vp_sub])
+            out["cube_ijk_np"] = ijk_sub if out["cube_ijk_np"] is None else np.vstack([out["cube_ijk_np"], ijk_sub])
+    finally:
+        loop.close()
+    # :172-173 thinning
+    out["vxl_mask_list"] = sparseCubes.filter_voxels(vxl_mask_list=[], prediction_list=out["prediction_list"], prob_thresh=tau,
+                                                     rayPooling_votes_list=out["rayPooling_votes_list"], rayPool_thresh=gamma * N_vp * 2)
+    return out

@@ -1,0 +1,78 @@
+"""GPU (-m gpu): reconstruct.reconstruct_scene (early rejection -> view-pair selection -> hot loop -> sparse lists, all on
+the GPU) against the same pipeline written the way main_reconstruct.py:67-173 writes it, with the drop-in modules called
+one by one through host arrays (each of them is parity-tested on its own against the reference goldens / the oracle)."""
+import numpy as np
+import pytest
+
+import golden_util
+
+pytestmark = pytest.mark.gpu
+PARAM_DT = [("xyz", np.float32, (3,)), ("ijk", np.uint32, (3,)), ("resol", np.float32)]
+MEAN_BGR = np.asarray([103.939, 116.779, 123.68]).astype(np.float32)
+MEAN_CVC = np.asarray([123.68, 116.779, 103.939, 123.68, 116.779, 103.939]).astype(np.float32)
+
+
+def test_reconstruct_scene_equals_reference_style_script(gpu_required):
+    import synth
+    from surfacenet_amd import CVC, SurfaceNet, camera, earlyRejection, reconstruct, runtime, similarityNet, sparseCubes, viewPairSelection, weights
+    runtime.reset()
+    cube_D, Dc, N_vp, resol = 16, 12, 2, np.float32(0.8)
+    cube_D_mm = resol * cube_D
+    P = golden_util.cameras()["P_dtu"][:4].copy()
+    P[:, :2, :] *= 0.5                                                     # 600x800 synthetic views of the DTU rig
+    imgs = [golden_util.synth_image(900 + v, 600, 800) for v in range(4)]
+    rs = np.random.RandomState(3)
+    N_cubes = 12
+    cubes = np.empty((N_cubes,), dtype=PARAM_DT)
+    cubes["xyz"] = (rs.rand(N_cubes, 3) * [80, 80, 40] + [-40, -40, 590]).astype(np.float32)
+    cubes["xyz"][5] = [2000, 2000, 100]                                    # projects outside every view
+    cubes["ijk"] = rs.randint(0, 40, (N_cubes, 3))
+    cubes["resol"] = resol
+    net_values = list(synth.calibrated_params(1))
+    simil_values = weights.synthetic_simil_param_values(6)
+    # make the logistic unit map the synthetic embedding distances into the accepted band 0.1 < p < 0.5
+    simil_values[28][:] = 3.0; simil_values[29][:] = -2.5   # identical (all-black) patches: sigmoid(-2.5) < 0.1 -> rejected
+    p2e, pair_fn = similarityNet.similarityNet_inference(None, (64, 64), param_values=simil_values)
+    relw_fn, net_fn = SurfaceNet.SurfaceNet_inference(N_vp, None, None, cube_D=cube_D, param_values=net_values)
+    min_prob, tau, gamma = 0.5, 0.6, 0.5
+
+    res = reconstruct.reconstruct_scene(imgs, P, cubes, cube_D_mm, cube_D, N_vp, p2e, pair_fn, relw_fn, cube_Dcenter=Dc, patches_mean_bgr=MEAN_BGR,
+                                        batchSize_similNet_patch2embedding=5, batchSize_similNet_embeddingPair2simil=7, batchSize_viewPair_w=13,
+                                        batchSize_nViewPair_SurfaceNet=4, min_prob=min_prob, tau=tau, gamma=gamma)
+
+    # ---- the reference's script, line by line, on the drop-in modules (host arrays everywhere) ----
+    cameraTs = camera.cameraPs2Ts(P)
+    ih, iw = camera.perspectiveProj_cubesCorner(P, cubes["xyz"], cube_D_mm, return_int_hw=False)
+    ch, cw = camera.perspectiveProj(P, cubes["xyz"] + cube_D_mm / 2., return_int_hw=False)
+    viewPairs = viewPairSelection.k_combination_np(range(4), k=2)
+    plain_p2e = lambda x: p2e(x)                                            # three-step crop / preprocess / embed protocol
+    emb, inscope = earlyRejection.patch2embedding(imgs, ih, iw, plain_p2e, MEAN_BGR, N_cubes, 4, 128, patchSize=64, batchSize=5,
+                                                  cubeCenter_hw=np.stack([ch, cw], axis=0))
+    dis = earlyRejection.embeddingPairs2simil(embeddings=emb, embeddingPair2simil_fn=pair_fn, inScope_cubes_vs_views=inscope, viewPairs=viewPairs,
+                                              N_views=4, batchSize=7)
+    valid = earlyRejection.selectFromSimilarity(dis, N_vp)
+    assert 0 < valid.sum() < N_cubes and not valid[5], np.round(dis, 3)    # the early rejection really rejects something
+    vp, w = viewPairSelection.viewPairSelection(cameraTs, emb, dis, valid, cubes["xyz"] + cube_D_mm / 2., relw_fn, 13, N_vp, viewPairs)
+    lists = ([], [], [], [], None, None, None)
+    p_l, rgb_l, ijk_l, v_l, cube_ijk, param_np, vp_np = lists
+    for _batch in reconstruct.gen_non0Batch_npBool(valid, 4):
+        X1 = CVC.gen_coloredCubes(selected_viewPairs=vp[_batch[valid]], xyz=cubes["xyz"][_batch], resol=cubes["resol"][_batch], colorize_cube_D=cube_D,
+                                  cameraPOs=P, models_img=imgs, visualization_ON=False)
+        _, X2 = CVC.preprocess_augmentation(None, X1, mean_rgb=MEAN_CVC[None, :, None, None, None], augment_ON=False, crop_ON=False)
+        fused, unfused = net_fn(X2, w[_batch[valid]])
+        rgb = runtime.context_for(cube_D).color_fuse(X2, unfused, w[_batch[valid]])
+        p_l, rgb_l, ijk_l, v_l, cube_ijk, param_np, vp_np = sparseCubes.append_dense_2sparseList(
+            prediction_sub=fused, rgb_sub=rgb, param_sub=cubes[_batch], viewPair_sub=vp[_batch[valid]], min_prob=min_prob, rayPool_thresh=0,
+            enable_centerCrop=True, cube_Dcenter=Dc, enable_rayPooling=True, cameraPOs=P, cameraTs=cameraTs, prediction_list=p_l, rgb_list=rgb_l,
+            vxl_ijk_list=ijk_l, rayPooling_votes_list=v_l, cube_ijk_np=cube_ijk, param_np=param_np, viewPair_np=vp_np)
+    masks = sparseCubes.filter_voxels(vxl_mask_list=[], prediction_list=p_l, prob_thresh=tau, rayPooling_votes_list=v_l, rayPool_thresh=gamma * N_vp * 2)
+
+    assert np.array_equal(res["patches_embedding"], emb) and np.array_equal(res["dissimilarity"], dis) and np.array_equal(res["validCubes"], valid)
+    assert np.array_equal(res["viewPairs4Reconstr"], vp) and np.array_equal(res["w_viewPairs4Reconstr"], w)
+    assert len(res["prediction_list"]) == len(p_l) > 0
+    for key, want in (("prediction_list", p_l), ("rgb_list", rgb_l), ("vxl_ijk_list", ijk_l), ("rayPooling_votes_list", v_l), ("vxl_mask_list", masks)):
+        assert all(np.array_equal(a, b) for a, b in zip(res[key], want)), key
+    assert np.array_equal(res["cube_ijk_np"], cube_ijk) and np.array_equal(res["viewPair_np"], vp_np)
+    assert np.array_equal(res["param_np"]["xyz"], param_np["xyz"]) and np.array_equal(res["param_np"]["resol"], param_np["resol"])
+    assert sum(int(m.sum()) for m in masks) > 0
+    runtime.reset()

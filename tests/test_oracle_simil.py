@@ -86,3 +86,12 @@ def test_simil_oracle_two_formulations_and_known_answers():
     s = simil_oracle.pair_similarity(e, values)
     w, bb = float(values[28].reshape(())), float(values[29].reshape(()))
     assert np.allclose(s[:, 0], [1 / (1 + np.exp(-bb)), 1 / (1 + np.exp(-(5 * w + bb)))])
+
+
+def test_camera_centres_doctest():
+    P = np.array([[798.693916, -2438.153488, 1568.674338, -542599.034996], [-44.838945, 1433.912029, 2576.399630, -1176685.647358],
+                  [-0.840873, -0.344537, 0.417405, 382.793511]])                      # utils/camera.py:91-95 doctest
+    t = np.array([555.64348632032, 191.10837560939, 360.02470478273])
+    assert np.allclose(camera.cameraPs2Ts(P[None])[0], t)
+    assert isinstance(camera.cameraPs2Ts([P]), list)
+    assert np.allclose(P @ np.r_[camera.cameraPs2Ts(P[None])[0], 1.0], 0, atol=1e-6)
