@@ -216,17 +216,28 @@ def main():
     ctx.set_images(scene["imgs"])
     d_pairs, d_xyz, d_resol, d_w = (ctx.upload(scene[k]) for k in ("pairs", "xyz", "resol", "w"))
     if use_dist:
-        t_fused = torch.empty(n * s3, dtype=torch.float32, device="cuda")
-        t_all = torch.empty(world * n * s3, dtype=torch.float32, device="cuda")
-        d_fused = t_fused.data_ptr()
+        # Double-buffered and host-sync free: the all-gather of step i (torch's stream) overlaps the kernels of step i+1 (the
+        # context's stream); the two streams are ordered against each other with events only.
+        t_fused = [torch.empty(n * s3, dtype=torch.float32, device="cuda") for _ in range(2)]
+        t_all = [torch.empty(world * n * s3, dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [None, None]
+        d_fused = [t.data_ptr() for t in t_fused]
+        sn_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device("cuda", local_rank))
+        comm_stream = torch.cuda.current_stream()
     else:
-        d_fused = ctx.dev_alloc(n * s3 * 4)
+        d_fused = [ctx.dev_alloc(n * s3 * 4)] * 2
+    step_no = [0]
 
     def step():
-        ctx.cvc_forward_dev(n, n_vp, d_pairs, d_xyz, d_resol, d_w, d_fused)
+        b = step_no[0] & 1
+        step_no[0] += 1
+        if use_dist and gathered[b] is not None:
+            sn_stream.wait_event(gathered[b])      # the all-gather that read this buffer two steps ago must be done first
+        ctx.cvc_forward_dev(n, n_vp, d_pairs, d_xyz, d_resol, d_w, d_fused[b])
         if use_dist:
-            ctx.synchronize()
-            dist.all_gather_into_tensor(t_all, t_fused)
+            comm_stream.wait_event(sn_stream.record_event())   # fused probabilities of this step are complete
+            dist.all_gather_into_tensor(t_all[b], t_fused[b])
+            gathered[b] = comm_stream.record_event()
 
     def barrier_sync():
         ctx.synchronize()
@@ -298,7 +309,12 @@ def main():
             out["similarity_net"] = simil_net(surfacenet_amd, ctx, scene, max(2, args.steps // 3))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, values, s, n_vp)
-        print(json.dumps(out))
+        try:   # RCCL's banner sits in the C stdio buffer: push it out first so that the JSON line is the last line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
     ctx.close()

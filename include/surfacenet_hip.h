@@ -112,6 +112,9 @@ void *sn_dev_alloc(sn_ctx *ctx, size_t bytes);
 int sn_dev_free(sn_ctx *ctx, void *p_dev);
 int sn_memcpy_h2d(sn_ctx *ctx, void *dst_dev, const void *src, size_t bytes);
 int sn_memcpy_d2h(sn_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
+/* The HIP stream (hipStream_t) every asynchronous entry point of this context is ordered on, for interop: record / wait
+ * events on it, or wrap it (e.g. torch.cuda.ExternalStream) to order collectives against the kernels without host syncs. */
+void *sn_stream(sn_ctx *ctx);
 /* Same as sn_cvc_forward with every array already in HBM. n*n_vp <= max_samples. mean6 is host. */
 int sn_cvc_forward_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
                        const float *resol_dev, const float *mean6, const float *w_dev, float *fused_dev,

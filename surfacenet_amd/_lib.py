@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SURFACENET_HIP_LIB") or os.path.join(_HERE, "libsurfa
 
 # Every symbol include/surfacenet_hip.h declares (tests/test_abi.py checks the two lists agree).
 ABI_SYMBOLS = [
-    "sn_create", "sn_destroy", "sn_last_error", "sn_version", "sn_synchronize", "sn_set_precision", "sn_get_precision",
+    "sn_create", "sn_destroy", "sn_last_error", "sn_version", "sn_synchronize", "sn_set_precision", "sn_get_precision", "sn_stream",
     "sn_load_weights", "sn_set_images", "sn_set_cameras",
     "sn_cvc", "sn_forward", "sn_cvc_forward", "sn_relative_weights", "sn_color_fuse", "sn_color_fuse_dev",
     "sn_dev_alloc", "sn_dev_free", "sn_memcpy_h2d", "sn_memcpy_d2h",
@@ -64,6 +64,7 @@ def load():
         "sn_synchronize": (c_int, [c_void_p]),
         "sn_set_precision": (c_int, [c_void_p, c_int]),
         "sn_get_precision": (c_int, [c_void_p]),
+        "sn_stream": (c_void_p, [c_void_p]),
         "sn_load_weights": (c_int, [c_void_p, c_void_p, c_size_t, P(ParamDesc), c_int]),
         "sn_set_images": (c_int, [c_void_p, c_int, P(c_void_p), P(c_int), P(c_int)]),
         "sn_set_cameras": (c_int, [c_void_p, c_int, c_void_p]),

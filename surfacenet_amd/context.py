@@ -44,6 +44,10 @@ class Context(object):
     def __exit__(self, *a):
         self.close()
 
+    def stream_handle(self):
+        """hipStream_t of this context as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return int(self._lib.sn_stream(self._h) or 0)
+
     def synchronize(self):
         _lib.check(self._lib.sn_synchronize(self._h))
 

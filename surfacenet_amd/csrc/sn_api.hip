@@ -600,6 +600,7 @@ int sn_set_precision(sn_ctx *c, int mode)
 }
 
 int sn_get_precision(sn_ctx *c) { return c ? c->split : SN_ERR_ARG; }
+void *sn_stream(sn_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int sn_synchronize(sn_ctx *c)
 {
