@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 DTYPE = {"f16m8": "f16 main term + fp8(e4m3, MX-scaled MFMA) correction terms, f32 accumulate (L_inf ~1e-4); CVC warp f64",
-         "f16x3": "f16x3 (each operand = hi+lo fp16 pair, 3 MFMAs per product, f32 accumulate: fp32-class results); CVC warp f64",
+         "f16x3": "f16x3 (each operand = hi+lo fp16 pair, 3 MFMAs per product, f32 accumulate: fp32-class results; the last 3x3x3 layer's two correction terms on one MX-fp8 MFMA); CVC warp f64",
+         "f16x3p": "f16x3 pure (each operand = hi+lo fp16 pair, 3 fp16 MFMAs per product in every layer, f32 accumulate); CVC warp f64",
          "f16": "f16 (MFMA, f32 accumulate); CVC warp f64"}
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak
 CNN_FLOPS_PER_SAMPLE_S32 = 44511690752   # learned-conv FLOPs per cube-view-pair at s=32
@@ -167,7 +168,7 @@ def main():
     ap.add_argument("--cube-d", type=int, default=32)
     ap.add_argument("--cubes", type=int, default=64, help="cubes per GPU per step")
     ap.add_argument("--n-vp", type=int, default=2)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16m8", "f16"],
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x3p", "f16m8", "f16"],
                     help="f16x3 (default): hi/lo split fp16 operands, fp32-class results (parity grade); f16: fast mode, L_inf ~2e-3")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16 fast-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -300,7 +301,7 @@ def main():
         except Exception:
             pass
         out["roofline"]["note"] = ("achieved = ALGORITHMIC conv FLOPs / kernel time; the f16x3 mode issues 3 MFMA FLOPs per algorithmic "
-                                   "FLOP, so its ceiling is frac = 1/3" if args.precision == "f16x3" else "achieved = algorithmic conv FLOPs / kernel time")
+                                   "FLOP (2 in the last 3x3x3 layer, whose correction terms run on the MX-fp8 MFMA), so its ceiling is frac = 1/3 .. 1/2" if args.precision.startswith("f16x3") else "achieved = algorithmic conv FLOPs / kernel time")
         if world == 1 and args.precision == "f16x3" and not args.no_fast_mode:
             out["fast_mode_f16"] = fast_mode(surfacenet_amd, scene, values, s, n, n_vp, local_rank, max(3, args.steps // 2))
         if world == 1 and not args.no_post_pass:

@@ -193,10 +193,12 @@ struct ConvCfg {
     static constexpr int MIN_WAVES_PER_SIMD = (NW == 8 || WG_PER_CU == 2) ? 2 : 1;
 };
 
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_, int K2D = 0>
+// OSPLIT: storage format of the OUTPUT tensor (defaults to SPLIT): lets an f16x3 layer feed an f16m8 layer.
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_, int K2D = 0, int OSPLIT_ = -1>
 __global__ void __launch_bounds__(NW_ * 64, (ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_, PADV_, K2D>::MIN_WAVES_PER_SIMD))
 conv3d_f16_mfma(ConvArgs a)
 {
+    constexpr int OSPLIT = OSPLIT_ < 0 ? SPLIT : OSPLIT_;
     using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH_, NW_, PADV_, K2D>;
     constexpr int NPL = C::NPL;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
@@ -546,7 +548,7 @@ conv3d_f16_mfma(ConvArgs a)
                         for (int r = 0; r < 4; ++r) {
                             float y = acc[m][n][r] * sc[r] + sh[r];
                             y = a.act == 0 ? fmaxf(y, 0.f) : sn_sigmoid(y);
-                            if constexpr (SPLIT == 1) {
+                            if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
                                 sn_split(y, hh, ll);
                                 h[r] = hh; l[r] = ll;
@@ -558,8 +560,8 @@ conv3d_f16_mfma(ConvArgs a)
                         const int ch = a.out_coff + nl;   // group-blocked layout: [b][ch/8][x][y][z][ch%8]
                         _Float16 *o = a.out + (size_t)b * VOL * a.out_cs + ((size_t)(ch >> 3) * VOL + vlin) * 8 + (ch & 7);
                         *reinterpret_cast<half4 *>(o) = h;
-                        if constexpr (SPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
-                        if constexpr (SPLIT == 2) {
+                        if constexpr (OSPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
+                        if constexpr (OSPLIT == 2) {
                             // second plane, 16-byte slot per (voxel, group): [fp8(hi) c0..c7 | fp8(lo*2^12) c0..c7]
                             char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.out_lo_off);
                             *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);

@@ -56,6 +56,7 @@ def test_cvc_bad_view_index(sn):
 #   emulates fp16 operand storage < 5e-3 (same noise class as the storage rounding itself, because a different
 #   summation order flips half-ulp fp16 roundings of stored activations)
 TOL_X3, TOL_F16_EMU, TOL_F16 = 1e-4, 5e-3, 1e-2
+TOL_X3P = 5e-5
 #   f16m8 (f16 main term + MX-fp8 correction terms): vs fp64 < 5e-4 (observed ~1e-4; north-star bar 1e-3); vs the oracle
 #   that emulates its storage/operand formats < 2e-4
 TOL_M8, TOL_M8_EMU = 5e-4, 2e-4
@@ -69,7 +70,7 @@ def _net_case(s, n, n_vp, seed):
     return values, X, w
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16m8", "f16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3p", "f16m8", "f16"])
 @pytest.mark.parametrize("s,n,n_vp", [(8, 3, 1), (16, 2, 2), (32, 1, 3)])
 def test_forward_vs_oracle(sn, s, n, n_vp, precision):
     from oracle import net_oracle
@@ -82,8 +83,10 @@ def test_forward_vs_oracle(sn, s, n, n_vp, precision):
     assert u64.std() > 0.05 and u64.min() < 0.2 and u64.max() > 0.8          # the test net is not degenerate
     e_ref, e_fused = np.abs(unfused - u64).max(), np.abs(fused - f64).max()
     print("%s s=%d: L_inf vs fp64 oracle: unfused %.3e fused %.3e" % (precision, s, e_ref, e_fused))
-    if precision == "f16x3":
+    if precision == "f16x3":         # default: f16x3 with merge_conv_b's correction terms on the MX-fp8 MFMA (observed ~2e-5)
         assert e_ref < TOL_X3 and e_fused < TOL_X3
+    elif precision == "f16x3p":      # every layer on three fp16 MFMAs (observed ~1e-5)
+        assert e_ref < TOL_X3P and e_fused < TOL_X3P
     elif precision == "f16m8":
         fm, um = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp, quant="f16m8")
         e_emu = np.abs(unfused - um).max()
