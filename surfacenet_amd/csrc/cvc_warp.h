@@ -44,7 +44,7 @@ __device__ __forceinline__ double sn_dot4(const double *p, double X, double Y, d
     return t;
 }
 
-__global__ void __launch_bounds__(256) cvc_warp_kernel(CvcArgs a)
+static __global__ void __launch_bounds__(256) cvc_warp_kernel(CvcArgs a)
 {
     const int s = a.s;
     const int s3 = s * s * s;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) cvc_warp_kernel(CvcArgs a)
 }
 
 // NCDHW fp32 (the reference's network input, already mean-subtracted) -> channels-last fp16 x0.
-__global__ void __launch_bounds__(256) ncdhw_to_x0_kernel(const float *X, _Float16 *x0, int s3, int nsamples, long long x0_lo_off, int x0_mode)
+static __global__ void __launch_bounds__(256) ncdhw_to_x0_kernel(const float *X, _Float16 *x0, int s3, int nsamples, long long x0_lo_off, int x0_mode)
 {
     const int vox = blockIdx.x * 256 + threadIdx.x;
     const int sample = blockIdx.y;

@@ -6,6 +6,7 @@
 //   fuse_kernel          ChannelPool_weightedAverage over the view pairs   nets/layers.py:325-336
 //   relw_*               the relative-weight MLP + grouped softmax         nets/SurfaceNet.py:84-100
 #pragma once
+// (Non-template kernels here are `static`: the header is included by several translation units of the library.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, 
 }
 
 // unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.
-__global__ void __launch_bounds__(256) fuse_kernel(const float *unfused, const float *w, float *fused, int n_vp, int s3, long long total)
+static __global__ void __launch_bounds__(256) fuse_kernel(const float *unfused, const float *w, float *fused, int n_vp, int s3, long long total)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(256) fuse_kernel(const float *unfused, const f
 // Voxel-level colour fusion, generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42; main_reconstruct.py:150-152),
 // float32 op for op: vw = w*pred; vw /= sum_p vw; mc = ((x_a+mean) + (x_b+mean))/2; rgb = uint8(sum_p vw*mc).
 // cvc (n*n_vp, 6, s3) is the MEAN-SUBTRACTED tensor the hot path produced (the caller's `X += mean` happens here).
-__global__ void __launch_bounds__(256) color_fuse_kernel(const float *cvc, const float *unfused, const float *w, unsigned char *rgb,
+static __global__ void __launch_bounds__(256) color_fuse_kernel(const float *cvc, const float *unfused, const float *w, unsigned char *rgb,
                                                          int n_vp, int s3, long long total, float m0, float m1, float m2, float m3,
                                                          float m4, float m5)
 {
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(256) color_fuse_kernel(const float *cvc, const
 }
 
 // Relative-weight MLP: one block (128 threads) per feature row. W1 (258,100) row-major fp32.
-__global__ void __launch_bounds__(128) relw_mlp_kernel(const float *feat, const float *W1, const float *scale1, const float *shift1,
+static __global__ void __launch_bounds__(128) relw_mlp_kernel(const float *feat, const float *W1, const float *scale1, const float *shift1,
                                                        const float *w2, float b2, float *z, int d_in, int n_hidden)
 {
     __shared__ float red[128];
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(128) relw_mlp_kernel(const float *feat, const 
     if (j == 0) z[row] = red[0] + b2;
 }
 
-__global__ void relw_softmax_kernel(const float *z, float *out, int n, int n_vp)
+static __global__ void relw_softmax_kernel(const float *z, float *out, int n, int n_vp)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;

@@ -1,48 +1,7 @@
 // sn_api.hip — C ABI (include/surfacenet_hip.h) over the gfx950 kernels: context, weight folding and
 // MFMA-fragment packing, activation workspace, the layer schedule of the SurfaceNet graph
 // (nets/SurfaceNet.py:18-76), and HIP-event profiling. Build: surfacenet_amd/csrc/Makefile.
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/surfacenet_hip.h"
-#include "conv3d_mfma.h"
-#include "cvc_warp.h"
-#include "elementwise.h"
-#include "postpass.h"
-#include "simil.h"
-
-using namespace sn;
-
-// ------------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-
-static int fail(int code, const char *fmt, ...)
-{
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-#define HIPCHK(expr)                                                                                       \
-    do {                                                                                                   \
-        hipError_t e_ = (expr);                                                                            \
-        if (e_ != hipSuccess) return fail(SN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+#include "sn_internal.h"
 
 // ------------------------------------------------------------------------------------------------
 // network description (restated from nets/SurfaceNet.py:18-76; order = weight-file order, App. B)
@@ -63,142 +22,6 @@ static const LayerSpec kSpecs[] = {
 static constexpr int kNumSpecs = sizeof(kSpecs) / sizeof(kSpecs[0]);
 static constexpr int kNetParams = 98, kAllParams = 105, kDFeature = 258, kHidden = 100;
 
-static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-
-// A conv layer prepared for conv3d_f16_mfma: packed fp16 weight fragments + folded BN.
-struct PackedConv {
-    std::string name;
-    int cin = 0, cout = 0, ks = 1, dil = 1, act = 0;
-    int cin_p = 0;             // input channels padded to 8
-    int nf = 0, nsplit = 1;    // 16-channel fragments per workgroup, workgroup columns
-    int cs8max = 4, split = 0, k2d = 0;   // k2d: ks x ks taps over (y,z) only (2-D nets)
-    std::vector<unsigned char> slab_c8;
-    long long wsplit_stride = 0;   // halfs
-    _Float16 *wpack = nullptr;     // device
-    float *scale = nullptr, *shift = nullptr;  // device, nsplit*nf*16
-    double macs_per_voxel = 0;
-};
-
-struct ProfRec { int tag; hipEvent_t e0, e1; double flops, bytes; };
-struct ProfStat { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
-
-struct sn_ctx {
-    int device = 0, s = 32, max_samples = 0;
-    hipStream_t stream = nullptr;
-    // images / cameras
-    int V_img = 0, V_cam = 0;
-    uint8_t *img_base = nullptr; long long *img_off = nullptr; int *img_h = nullptr, *img_w = nullptr;
-    double *cams = nullptr;
-    // weights
-    bool have_weights = false, have_relw = false;
-    int split = 1;              // 0: f16 operands; 1: f16x3 (hi/lo split operands, fp32-class results) — default; 2: f16m8
-    int mode = 1;               // the SN_PRECISION_* value given to sn_set_precision
-    bool tail_m8 = true;        // f16x3: merge_conv_b (the last 3x3x3 layer) runs its two correction terms on the MX-fp8 MFMA
-    bool ws_ready = false; int ws_split = -1;
-    std::map<std::string, PackedConv> conv;
-    float *w3 = nullptr; float scale3 = 0, shift3 = 0;
-    void *zero_page = nullptr; int num_cus = 256;
-    void *rccl_comm = nullptr; int comm_world = 0, comm_rank = 0;   // RCCL communicator (lazy dlopen of librccl)
-    float *relw_W1 = nullptr, *relw_scale = nullptr, *relw_shift = nullptr, *relw_w2 = nullptr; float relw_b2 = 0;
-    // activation workspace (channels-last fp16)
-    _Float16 *x0 = nullptr, *a1 = nullptr, *b1 = nullptr, *cat = nullptr, *p1 = nullptr, *a2 = nullptr, *b2 = nullptr,
-             *p2 = nullptr, *a3 = nullptr, *b3 = nullptr, *a4 = nullptr, *b4 = nullptr, *s2 = nullptr, *s3 = nullptr,
-             *s4 = nullptr, *ma = nullptr;
-    std::vector<void *> ws_owned;
-    float *unf_ws = nullptr;      // [max_samples][s^3]
-    // batch parameter staging
-    int64_t *d_pairs = nullptr; float *d_xyz = nullptr, *d_resol = nullptr, *d_w = nullptr;
-    // host-API staging
-    float *d_X = nullptr;         // [max_samples][6][s^3] fp32 NCDHW
-    float *d_fused = nullptr;     // [max_samples][s^3]
-    std::vector<long long> h_img_off; std::vector<int> h_img_h, h_img_w;   // host copies (patch cropping addresses one view)
-    // similarityNet (N3)
-    PackedConv sconv[13]; bool simil_loaded = false; int simil_split = -1;
-    float *semb_W = nullptr, *semb_b = nullptr; float ssim_w = 0, ssim_b = 0;
-    std::vector<float> simil_host;   // the 13 conv layers' fp32 parameters, kept to re-pack on a precision switch
-    std::vector<sn_param_desc> simil_descs;
-    void *sws = nullptr; size_t sws_bytes = 0; int sws_n = 0, sws_split = -1;
-    // post-pass (ray pooling / dense2sparse) workspace
-    void *rp_ws = nullptr; size_t rp_ws_bytes = 0; int *d_err = nullptr; int *d_counts = nullptr; int d_counts_cap = 0;
-    std::vector<void *> owned;
-    // profiling
-    bool prof_on = false;
-    std::vector<ProfRec> prof_recs;
-    std::vector<ProfStat> prof_stats;
-    std::map<std::string, int> prof_tags;
-    std::vector<hipEvent_t> ev_pool;
-};
-
-template <typename T>
-static int dev_alloc(sn_ctx *c, T **p, size_t count)
-{
-    void *q = nullptr;
-    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
-    if (e != hipSuccess) return fail(SN_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-    c->owned.push_back(q);
-    *p = static_cast<T *>(q);
-    return SN_OK;
-}
-
-static int dev_free_owned(sn_ctx *c, void *p)
-{
-    if (!p) return SN_OK;
-    auto it = std::find(c->owned.begin(), c->owned.end(), p);
-    if (it != c->owned.end()) c->owned.erase(it);
-    HIPCHK(hipFree(p));
-    return SN_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// profiling: every launch goes through prof_begin / prof_end
-// ------------------------------------------------------------------------------------------------
-static hipEvent_t get_event(sn_ctx *c)
-{
-    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
-    return e;
-}
-
-struct ProfScope {
-    sn_ctx *c; ProfRec r; bool on;
-    ProfScope(sn_ctx *ctx, const std::string &tag, double flops, double bytes) : c(ctx), on(ctx->prof_on)
-    {
-        if (!on) return;
-        auto it = c->prof_tags.find(tag);
-        int id;
-        if (it == c->prof_tags.end()) {
-            id = (int)c->prof_stats.size();
-            c->prof_tags[tag] = id;
-            ProfStat st; st.name = tag;
-            c->prof_stats.push_back(st);
-        } else id = it->second;
-        r.tag = id; r.flops = flops; r.bytes = bytes;
-        r.e0 = get_event(c); r.e1 = get_event(c);
-        (void)hipEventRecord(r.e0, c->stream);
-    }
-    ~ProfScope()
-    {
-        if (!on) return;
-        (void)hipEventRecord(r.e1, c->stream);
-        c->prof_recs.push_back(r);
-    }
-};
-
-static int prof_drain(sn_ctx *c)
-{
-    if (c->prof_recs.empty()) return SN_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (auto &r : c->prof_recs) {
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
-        ProfStat &st = c->prof_stats[r.tag];
-        st.ms += ms; st.launches += 1; st.flops += r.flops; st.bytes += r.bytes;
-        c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1);
-    }
-    c->prof_recs.clear();
-    return SN_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 // weight preparation
@@ -231,8 +54,8 @@ static unsigned char fp8_e4m3(float v)
 //   split 2 (f16m8): [slab][piece of 8 groups]{ chunk 2p: nf hi fragments | chunk 2p+1: nf hi fragments |
 //                     nf MX fragments (2 KiB: k bytes 0-15 of all 64 lanes, then 16-31); lane (row = l&15, q = l>>4): q<2 -> fp8(w_lo * 2^12) of
 //                     groups 8p+4q..+3, q>=2 -> fp8(w_hi) of groups 8p+4(q-2)..+3 }   (every piece is full-size, zero padded)
-static int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const float *gamma, const float *mean,
-                     const float *inv_std, int nf, int nsplit, int cs8max, int split)
+int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const float *gamma, const float *mean,
+              const float *inv_std, int nf, int nsplit, int cs8max, int split)
 {
     L.nf = nf; L.nsplit = nsplit; L.cs8max = cs8max; L.split = split;
     L.cin_p = round_up(L.cin, 8);
@@ -334,14 +157,6 @@ static int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta
     return SN_OK;
 }
 
-static bool shape_is(const sn_param_desc &d, std::initializer_list<int> s)
-{
-    if (d.ndim != (int)s.size()) return false;
-    int i = 0;
-    for (int v : s) if (d.shape[i++] != v) return false;
-    return true;
-}
-
 struct TileChoice { int nf, nsplit, cs8max; };
 // Must agree with the kernel instantiations in run_net_t<SPLIT> (launch_conv verifies it).
 static TileChoice tile_for(const LayerSpec &sp, int split)
@@ -352,56 +167,6 @@ static TileChoice tile_for(const LayerSpec &sp, int split)
     if (sp.cout == 80) return {5, 1, split == 2 ? 1 : 2};
     if (sp.cout == 160) return {5, 2, split == 2 ? 1 : 2};
     return {7, 1, 1};  // cout 100
-}
-
-// ------------------------------------------------------------------------------------------------
-// launches
-// ------------------------------------------------------------------------------------------------
-// A channels-last fp16 activation tensor: hi plane at p, lo plane (f16x3 mode) at p + lo elements.
-struct Act { _Float16 *p; long long lo; };
-
-template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH, int NW, int PADV, int K2D = 0, int OSPLIT = -1>
-static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act out, int out_cs, int out_coff, int out_cp,
-                       float *out_f32, int B, int D, int DX = 0)
-{
-    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV, K2D>;
-    if (DX <= 0) DX = D;
-    if ((L.k2d != 0) != (K2D != 0)) return fail(SN_ERR_STATE, "%s: packed for a different tap geometry", L.name.c_str());
-    if (L.nf != NF || L.ks != KS || L.dil != DIL || L.cs8max != C::CS8MAX || L.split != SPLIT)
-        return fail(SN_ERR_STATE, "%s: packed for a different kernel configuration", L.name.c_str());
-    ConvArgs a;
-    memset(&a, 0, sizeof a);
-    a.in = in.p; a.in_lo_off = in.lo; a.out = out.p; a.out_lo_off = out.lo; a.out_f32 = out_f32;
-    a.wpack = L.wpack; a.scale = L.scale; a.shift = L.shift;
-    a.w3 = c->w3; a.scale3 = c->scale3; a.shift3 = c->shift3; a.zero_page = c->zero_page;
-    a.wsplit_stride = L.wsplit_stride;
-    a.in_cs = in_cs; a.out_cs = out_cs; a.out_coff = out_coff; a.out_cp = out_cp;
-    a.D = D; a.DX = DX;
-    a.tiles_x = (DX + C::TX - 1) / C::TX; a.tiles_y = (D + C::TY - 1) / C::TY; a.tiles_z = (D + C::TZ - 1) / C::TZ;
-    a.total_tiles = B * a.tiles_x * a.tiles_y * a.tiles_z;
-    a.act = L.act;
-    a.nslab = (int)L.slab_c8.size();
-    for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
-    const double vox = (double)B * DX * D * D;
-    const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : L.cout));
-    ProfScope ps(c, L.name, 2.0 * L.macs_per_voxel * vox, bytes);
-    // persistent workgroups: one resident set, each walking tiles blockIdx.x, +gridDim.x, ...
-    const int resident = std::max(1, c->num_cus * C::WG_PER_CU / L.nsplit);
-    dim3 grid((unsigned)std::min(a.total_tiles, resident), (unsigned)L.nsplit);
-    {
-        // phase-staggered start (only worthwhile when every workgroup walks many tiles): a quarter of the estimated tile time
-        static const int stag = getenv("SN_STAGGER") ? atoi(getenv("SN_STAGGER")) : 0;
-        const int tiles_per_wg = a.total_tiles / (int)grid.x;
-        if (stag && EPI == EPI_STORE && tiles_per_wg >= 8) {
-            double chunks = 0;
-            for (unsigned char c8n : L.slab_c8) chunks += (C::NTAP * c8n + 3) / 4;
-            const double units = chunks * MF * NF * (SPLIT == 1 ? 3.0 : (SPLIT == 2 ? 2.2 : 1.0));
-            a.stagger_clk = (int)(units * 19.5 * 2.0 * 1.3 / 4.0) * stag;
-        }
-    }
-    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV, K2D, OSPLIT>), grid, dim3(NW * 64), 0, c->stream, a);
-    HIPCHK(hipGetLastError());
-    return SN_OK;
 }
 
 template <int SPLIT>
@@ -996,490 +761,6 @@ int sn_color_fuse(sn_ctx *c, int n, int n_vp, const float *cvc, const float *mea
     (void)hipFree(d_c); (void)hipFree(d_u); (void)hipFree(d_wt); (void)hipFree(d_r);
     if (e != hipSuccess) return fail(SN_ERR_HIP, "sn_color_fuse: %s", hipGetErrorString(e));
     return rc;
-}
-
-// ---- post-pass: ray pooling + dense2sparse --------------------------------------------------------
-static int check_pairs_cam(sn_ctx *c, long long count, const int64_t *pairs, std::vector<int64_t> &wrapped)
-{
-    wrapped.assign(pairs, pairs + count);
-    for (long long i = 0; i < count; ++i) {
-        int64_t v = wrapped[i];
-        if (v < -(int64_t)c->V_cam || v >= (int64_t)c->V_cam)
-            return fail(SN_ERR_ARG, "view index %lld out of range for %d cameras (the reference raises IndexError here)", (long long)v, c->V_cam);
-        if (v < 0) wrapped[i] = v + c->V_cam;
-    }
-    return SN_OK;
-}
-
-static int launch_ray_pool(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, const float *xyz_dev, const float *resol_dev,
-                           const float *pred_dev, int use_thresh, float min_prob, unsigned char *votes_dev)
-{
-    if (!c->cams) return fail(SN_ERR_STATE, "sn_set_cameras must be called before ray pooling");
-    if (2 * n_vp > 255) return fail(SN_ERR_ARG, "2*n_vp = %d votes do not fit the uint8 result", 2 * n_vp);
-    const size_t s3 = (size_t)c->s * c->s * c->s;
-    size_t cap = 64;
-    while (cap < 2 * s3) cap <<= 1;
-    const size_t per_wg = cap * (8 + 8 + 8 + 4) + s3 * 4;
-    const int E = 2 * n_vp;
-    const size_t budget = (size_t)1 << 30;                      // hash-table workspace per launch
-    int cubes = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / (per_wg * E)));
-    const size_t need = per_wg * E * cubes;
-    if (!c->d_err) { int rc = dev_alloc(c, &c->d_err, 1); if (rc != SN_OK) return rc; HIPCHK(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream)); }
-    if (c->rp_ws_bytes < need) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->rp_ws) dev_free_owned(c, c->rp_ws);
-        c->rp_ws = nullptr; c->rp_ws_bytes = 0;
-        unsigned char *w = nullptr;
-        int rc = dev_alloc(c, &w, need);
-        if (rc != SN_OK) return rc;
-        c->rp_ws = w; c->rp_ws_bytes = need;
-    }
-    HIPCHK(hipMemsetAsync(votes_dev, 0, (size_t)n * s3, c->stream));
-    for (int i0 = 0; i0 < n; i0 += cubes) {
-        const int m = std::min(cubes, n - i0);
-        const size_t wgs = (size_t)m * E;
-        RayPoolArgs a;
-        memset(&a, 0, sizeof a);
-        a.pairs = pairs_dev + (size_t)i0 * E; a.xyz = xyz_dev + 3 * (size_t)i0; a.resol = resol_dev + i0; a.cams = c->cams;
-        a.pred = pred_dev + (size_t)i0 * s3; a.votes = votes_dev + (size_t)i0 * s3;
-        unsigned char *w = static_cast<unsigned char *>(c->rp_ws);
-        a.pix_key = reinterpret_cast<unsigned long long *>(w); w += wgs * cap * 8;
-        a.pix_best = reinterpret_cast<unsigned long long *>(w); w += wgs * cap * 8;
-        a.cell_key = reinterpret_cast<unsigned long long *>(w); w += wgs * cap * 8;
-        a.cell_idx = reinterpret_cast<unsigned *>(w); w += wgs * cap * 4;
-        a.cslot = reinterpret_cast<unsigned *>(w);
-        a.err = c->d_err;
-        a.n_vp = n_vp; a.s = c->s; a.V = c->V_cam; a.cap_max = (int)cap; a.use_thresh = use_thresh; a.thresh = min_prob;
-        // algorithmic bytes: the prediction cube is read once per distinct view (<= E), the votes are written once
-        ProfScope ps(c, "ray_pool", 0, (double)m * s3 * (4.0 * E + 1.0));
-        hipLaunchKernelGGL(ray_pool_kernel, dim3((unsigned)E, (unsigned)m), dim3(RP_NT), 0, c->stream, a);
-        HIPCHK(hipGetLastError());
-    }
-    return SN_OK;
-}
-
-extern "C" int sn_ray_pool_dev(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, const float *xyz_dev, const float *resol_dev,
-                               const float *pred_dev, int use_thresh, float min_prob, unsigned char *votes_dev)
-{
-    if (!c || !pairs_dev || !xyz_dev || !resol_dev || !pred_dev || !votes_dev) return fail(SN_ERR_ARG, "null argument");
-    if (n < 1 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
-    HIPCHK(hipSetDevice(c->device));
-    return launch_ray_pool(c, n, n_vp, pairs_dev, xyz_dev, resol_dev, pred_dev, use_thresh, min_prob, votes_dev);
-}
-
-static int sparse_geometry(sn_ctx *c, const sn_sparse_cfg *cfg, int &lo, int &dc)
-{
-    lo = 0; dc = c->s;
-    if (cfg->enable_centerCrop) {
-        if (cfg->cube_Dcenter < 1 || cfg->cube_Dcenter > c->s) return fail(SN_ERR_ARG, "cube_Dcenter %d not in [1,%d]", cfg->cube_Dcenter, c->s);
-        lo = (c->s - cfg->cube_Dcenter) / 2; dc = cfg->cube_Dcenter;
-    }
-    if (dc > 256) return fail(SN_ERR_ARG, "voxel indices are uint8 (utils/sparseCubes.py:68): cube edge %d > 256", dc);
-    return SN_OK;
-}
-
-extern "C" int sn_dense2sparse_dev(sn_ctx *c, int n, int n_vp, const int64_t *pairs_dev, const float *xyz_dev, const float *resol_dev,
-                                   const float *pred_dev, const unsigned char *rgb_dev, const sn_sparse_cfg *cfg,
-                                   unsigned char *votes_ws_dev, int64_t *offsets_dev, unsigned char *ijk_dev, uint16_t *pred16_dev,
-                                   unsigned char *rgb_out_dev, unsigned char *votes_out_dev)
-{
-    if (!c || !cfg || !pred_dev || !offsets_dev || !ijk_dev || !pred16_dev) return fail(SN_ERR_ARG, "null argument");
-    if (n < 1 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
-    HIPCHK(hipSetDevice(c->device));
-    int lo, dc, rc;
-    if ((rc = sparse_geometry(c, cfg, lo, dc)) != SN_OK) return rc;
-    const bool by_votes = cfg->enable_rayPooling && cfg->rayPool_thresh != 0;      // sparseCubes.py:60-62
-    const bool need_votes = cfg->enable_rayPooling && (by_votes || votes_out_dev);
-    if (need_votes) {
-        if (!pairs_dev || !xyz_dev || !resol_dev || !votes_ws_dev) return fail(SN_ERR_ARG, "ray pooling needs view pairs, xyz, resol and the votes scratch");
-        if ((rc = launch_ray_pool(c, n, n_vp, pairs_dev, xyz_dev, resol_dev, pred_dev, 1, cfg->min_prob, votes_ws_dev)) != SN_OK) return rc;
-    }
-    if (c->d_counts_cap < n) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->d_counts) dev_free_owned(c, c->d_counts);
-        c->d_counts = nullptr; c->d_counts_cap = 0;
-        if ((rc = dev_alloc(c, &c->d_counts, (size_t)n)) != SN_OK) return rc;
-        c->d_counts_cap = n;
-    }
-    SparseArgs a;
-    memset(&a, 0, sizeof a);
-    a.pred = pred_dev; a.rgb = rgb_out_dev ? rgb_dev : nullptr; a.votes = need_votes ? votes_ws_dev : nullptr;
-    a.offsets = reinterpret_cast<long long *>(offsets_dev); a.counts = c->d_counts;
-    a.ijk = ijk_dev; a.pred16 = pred16_dev; a.rgb_out = rgb_out_dev; a.votes_out = votes_out_dev;
-    a.s = c->s; a.lo = lo; a.dc = dc;
-    a.by_votes = by_votes ? 1 : 0; a.vote_thresh = cfg->rayPool_thresh; a.min_prob = cfg->min_prob;
-    const double vox = (double)n * dc * dc * dc;
-    // algorithmic bytes: the keep rule reads 4 B (pred) or 1 B (votes) per voxel twice (count + write); kept voxels add <= 9 B
-    ProfScope ps(c, "dense2sparse", 0, vox * (by_votes ? 1.0 : 4.0) * 2.0);
-    hipLaunchKernelGGL(d2s_count_kernel, dim3((unsigned)n), dim3(D2S_NT), 0, c->stream, a);
-    hipLaunchKernelGGL(d2s_scan_kernel, dim3(1), dim3(64), 0, c->stream, c->d_counts, a.offsets, n);
-    hipLaunchKernelGGL(d2s_write_kernel, dim3((unsigned)n), dim3(D2S_NT), 0, c->stream, a);
-    HIPCHK(hipGetLastError());
-    return SN_OK;
-}
-
-// Host-array forms: stage through temporary device buffers, synchronous.
-extern "C++" {
-struct TmpDev {
-    std::vector<void *> p;
-    ~TmpDev() { for (void *q : p) (void)hipFree(q); }
-    template <typename T> T *get(size_t count) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return static_cast<T *>(q); }
-};
-}
-
-extern "C" int sn_ray_pool(sn_ctx *c, int n, int n_vp, const int64_t *pairs, const float *xyz, const float *resol, const float *pred,
-                           int use_thresh, float min_prob, unsigned char *votes)
-{
-    if (!c || !pairs || !xyz || !resol || !pred || !votes) return fail(SN_ERR_ARG, "null argument");
-    if (n < 0 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
-    if (n == 0) return SN_OK;
-    if (!c->cams) return fail(SN_ERR_STATE, "sn_set_cameras must be called before ray pooling");
-    HIPCHK(hipSetDevice(c->device));
-    std::vector<int64_t> wp;
-    int rc;
-    if ((rc = check_pairs_cam(c, (long long)n * n_vp * 2, pairs, wp)) != SN_OK) return rc;
-    const size_t s3 = (size_t)c->s * c->s * c->s;
-    TmpDev t;
-    int64_t *d_p = t.get<int64_t>((size_t)n * n_vp * 2); float *d_x = t.get<float>(3 * (size_t)n), *d_r = t.get<float>(n), *d_pr = t.get<float>(n * s3);
-    unsigned char *d_v = t.get<unsigned char>(n * s3);
-    if (!d_p || !d_x || !d_r || !d_pr || !d_v) return fail(SN_ERR_NOMEM, "sn_ray_pool: device allocation failed");
-    HIPCHK(hipMemcpyAsync(d_p, wp.data(), sizeof(int64_t) * 2 * n * n_vp, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_x, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_r, resol, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_pr, pred, sizeof(float) * n * s3, hipMemcpyHostToDevice, c->stream));
-    if ((rc = launch_ray_pool(c, n, n_vp, d_p, d_x, d_r, d_pr, use_thresh, min_prob, d_v)) != SN_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
-    HIPCHK(hipMemcpyAsync(votes, d_v, n * s3, hipMemcpyDeviceToHost, c->stream));
-    return sn_synchronize(c);
-}
-
-extern "C" int sn_dense2sparse(sn_ctx *c, int n, int n_vp, const int64_t *pairs, const float *xyz, const float *resol, const float *pred,
-                               const unsigned char *rgb, const sn_sparse_cfg *cfg, int64_t *offsets, unsigned char *ijk,
-                               uint16_t *pred16, unsigned char *rgb_out, unsigned char *votes_out)
-{
-    if (!c || !cfg || !pred || !offsets || !ijk || !pred16) return fail(SN_ERR_ARG, "null argument");
-    if (rgb_out && !rgb) return fail(SN_ERR_ARG, "rgb_out requested without rgb");
-    if (n < 0 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
-    if (n == 0) { offsets[0] = 0; return SN_OK; }
-    HIPCHK(hipSetDevice(c->device));
-    int lo, dc, rc;
-    if ((rc = sparse_geometry(c, cfg, lo, dc)) != SN_OK) return rc;
-    const size_t s3 = (size_t)c->s * c->s * c->s, cap = (size_t)n * dc * dc * dc;
-    TmpDev t;
-    int64_t *d_p = nullptr; float *d_x = nullptr, *d_r = nullptr; unsigned char *d_vws = nullptr;
-    std::vector<int64_t> wp;
-    if (cfg->enable_rayPooling) {
-        if (!pairs || !xyz || !resol) return fail(SN_ERR_ARG, "ray pooling needs view pairs, xyz and resol");
-        if (!c->cams) return fail(SN_ERR_STATE, "sn_set_cameras must be called before ray pooling");
-        if ((rc = check_pairs_cam(c, (long long)n * n_vp * 2, pairs, wp)) != SN_OK) return rc;
-        d_p = t.get<int64_t>((size_t)n * n_vp * 2); d_x = t.get<float>(3 * (size_t)n); d_r = t.get<float>(n); d_vws = t.get<unsigned char>(n * s3);
-        if (!d_p || !d_x || !d_r || !d_vws) return fail(SN_ERR_NOMEM, "sn_dense2sparse: device allocation failed");
-        HIPCHK(hipMemcpyAsync(d_p, wp.data(), sizeof(int64_t) * 2 * n * n_vp, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(d_x, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(d_r, resol, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-    }
-    float *d_pr = t.get<float>(n * s3);
-    unsigned char *d_rgb = rgb_out ? t.get<unsigned char>(3 * n * s3) : nullptr;
-    int64_t *d_off = t.get<int64_t>((size_t)n + 1);
-    unsigned char *d_ijk = t.get<unsigned char>(3 * cap), *d_ro = rgb_out ? t.get<unsigned char>(3 * cap) : nullptr;
-    unsigned char *d_vo = (votes_out && cfg->enable_rayPooling) ? t.get<unsigned char>(cap) : nullptr;
-    uint16_t *d_p16 = t.get<uint16_t>(cap);
-    if (!d_pr || !d_off || !d_ijk || !d_p16 || (rgb_out && (!d_rgb || !d_ro)) || (votes_out && cfg->enable_rayPooling && !d_vo))
-        return fail(SN_ERR_NOMEM, "sn_dense2sparse: device allocation failed");
-    HIPCHK(hipMemcpyAsync(d_pr, pred, sizeof(float) * n * s3, hipMemcpyHostToDevice, c->stream));
-    if (rgb_out) HIPCHK(hipMemcpyAsync(d_rgb, rgb, 3 * n * s3, hipMemcpyHostToDevice, c->stream));
-    rc = sn_dense2sparse_dev(c, n, n_vp, d_p, d_x, d_r, d_pr, d_rgb, cfg, d_vws, d_off, d_ijk, d_p16, d_ro, d_vo);
-    if (rc != SN_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
-    HIPCHK(hipMemcpyAsync(offsets, d_off, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, c->stream));
-    if ((rc = sn_synchronize(c)) != SN_OK) return rc;
-    const size_t total = (size_t)offsets[n];
-    if (total) {
-        HIPCHK(hipMemcpyAsync(ijk, d_ijk, 3 * total, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(pred16, d_p16, 2 * total, hipMemcpyDeviceToHost, c->stream));
-        if (rgb_out) HIPCHK(hipMemcpyAsync(rgb_out, d_ro, 3 * total, hipMemcpyDeviceToHost, c->stream));
-        if (d_vo) HIPCHK(hipMemcpyAsync(votes_out, d_vo, total, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    return SN_OK;
-}
-
-// ---- similarityNet + patch cropping ---------------------------------------------------------------
-// 13 x (3x3 conv + bias + ReLU) on the 2-D form of the MFMA kernel; a chunk of n patches is one volume (x = patch index).
-static const int kSimC[14] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};   // channel chain
-static const int kSimStage[13] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4};                          // H = 64 >> stage
-static const char *const kSimName[13] = {"s_conv1_1", "s_conv1_2", "s_conv2_1", "s_conv2_2", "s_conv3_1", "s_conv3_2", "s_conv3_3",
-                                         "s_conv4_1", "s_conv4_2", "s_conv4_3", "s_conv5_1", "s_conv5_2", "s_conv5_3"};
-static constexpr int kSimParams = 30, kSimChunk = 2048, kSimNF = 4, kSimCS8 = 2;
-#define SCONV 3, 1, 4, kSimNF, EPI_STORE, SP, kSimCS8, 2, 8, 0, 1
-// the 4x4 maps of conv5_x: one MFMA voxel fragment = one image (K2D = 2), 16 images x 128 output channels per workgroup
-#define SCONV5 3, 1, 2, 8, EPI_STORE, SP, kSimCS8, 2, 8, 0, 2
-static int simil_nf(int i) { return kSimStage[i] == 4 ? 8 : kSimNF; }
-
-static int simil_mode(sn_ctx *c) { return c->split == 0 ? 0 : 1; }   // f16m8 contexts run this net in f16x3 (own workspace)
-
-static int simil_pack(sn_ctx *c)
-{
-    const int want = simil_mode(c);
-    if (c->simil_split == want) return SN_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    int rc;
-    for (int i = 0; i < 13; ++i) {
-        PackedConv &L = c->sconv[i];
-        dev_free_owned(c, L.wpack); dev_free_owned(c, L.scale); dev_free_owned(c, L.shift);
-        L = PackedConv();
-        L.name = kSimName[i]; L.cin = kSimC[i]; L.cout = kSimC[i + 1]; L.ks = 3; L.dil = 1; L.act = 0; L.k2d = 1;
-        const float *W = c->simil_host.data() + c->simil_descs[2 * i].offset, *b = c->simil_host.data() + c->simil_descs[2 * i + 1].offset;
-        std::vector<float> one((size_t)L.cout, 1.f), zero((size_t)L.cout, 0.f);
-        if ((rc = pack_conv(c, L, W, b, one.data(), zero.data(), one.data(), simil_nf(i), L.cout / (16 * simil_nf(i)), kSimCS8, want)) != SN_OK) return rc;
-    }
-    c->simil_split = want;
-    return SN_OK;
-}
-
-extern "C" int sn_simil_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params)
-{
-    if (!c || !blob || !descs) return fail(SN_ERR_ARG, "null argument");
-    if (n_params != kSimParams) return fail(SN_ERR_ARG, "similarityNet has %d parameter arrays, got %d", kSimParams, n_params);
-    HIPCHK(hipSetDevice(c->device));
-    auto count = [](const sn_param_desc &d) { size_t n = 1; for (int i = 0; i < d.ndim; ++i) n *= (size_t)d.shape[i]; return n; };
-    for (int i = 0; i < n_params; ++i)
-        if (descs[i].ndim < 1 || descs[i].ndim > 5 || descs[i].offset < 0 || (size_t)descs[i].offset + count(descs[i]) > n_floats)
-            return fail(SN_ERR_ARG, "param %d: bad descriptor", i);
-    for (int i = 0; i < 13; ++i) {
-        if (!shape_is(descs[2 * i], {kSimC[i + 1], kSimC[i], 3, 3})) return fail(SN_ERR_ARG, "%s: W must be (%d,%d,3,3)", kSimName[i], kSimC[i + 1], kSimC[i]);
-        if (!shape_is(descs[2 * i + 1], {kSimC[i + 1]})) return fail(SN_ERR_ARG, "%s: b must be (%d,)", kSimName[i], kSimC[i + 1]);
-    }
-    if (!shape_is(descs[26], {kSimilFeat, kEmb}) || !shape_is(descs[27], {kEmb})) return fail(SN_ERR_ARG, "embedding: W must be (%d,%d), b (%d,)", kSimilFeat, kEmb, kEmb);
-    if (!shape_is(descs[28], {1, 1}) || !shape_is(descs[29], {1})) return fail(SN_ERR_ARG, "similarity: W must be (1,1), b (1,)");
-    c->simil_host.assign(blob, blob + n_floats);
-    c->simil_descs.assign(descs, descs + n_params);
-    c->simil_split = -1; c->simil_loaded = false;
-    int rc;
-    if (!c->semb_W) { if ((rc = dev_alloc(c, &c->semb_W, (size_t)kSimilFeat * kEmb)) != SN_OK) return rc; if ((rc = dev_alloc(c, &c->semb_b, kEmb)) != SN_OK) return rc; }
-    HIPCHK(hipMemcpy(c->semb_W, blob + descs[26].offset, sizeof(float) * kSimilFeat * kEmb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->semb_b, blob + descs[27].offset, sizeof(float) * kEmb, hipMemcpyHostToDevice));
-    c->ssim_w = blob[descs[28].offset]; c->ssim_b = blob[descs[29].offset];
-    if ((rc = simil_pack(c)) != SN_OK) return rc;
-    c->simil_loaded = true;
-    return SN_OK;
-}
-
-// Workspace of one chunk: every tensor [C/8][cap][H][H][8] fp16 (+ second plane right behind), carved from one allocation.
-struct SimilWs {
-    Act p0, a[5][2], pool[5];
-    float *feat, *emb, *part; double *centers; unsigned char *patches;
-};
-static size_t simil_carve(sn_ctx *c, int cap, int npl, SimilWs *w)
-{
-    size_t off = 0;
-    char *base = static_cast<char *>(c->sws);
-    auto act = [&](int ch, int H) {
-        const size_t halfs = (size_t)ch * H * H * cap;
-        Act t{base ? reinterpret_cast<_Float16 *>(base + off) : nullptr, (long long)halfs};
-        off += halfs * 2 * npl;
-        off = (off + 255) / 256 * 256;
-        return t;
-    };
-    static const int C[5] = {64, 128, 256, 512, 512};
-    SimilWs t;
-    t.p0 = act(8, kPatch);
-    for (int st = 0; st < 5; ++st) {
-        const int H = kPatch >> st;
-        t.a[st][0] = act(C[st], H); t.a[st][1] = act(C[st], H); t.pool[st] = act(C[st], H / 2);
-    }
-    auto raw = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
-    t.feat = reinterpret_cast<float *>(raw((size_t)cap * kSimilFeat * 4));
-    t.emb = reinterpret_cast<float *>(raw((size_t)cap * kEmb * 4));
-    t.part = reinterpret_cast<float *>(raw((size_t)cap * kEmb * 4 * kDenseKS));
-    t.centers = reinterpret_cast<double *>(raw((size_t)cap * 2 * 8));
-    t.patches = reinterpret_cast<unsigned char *>(raw((size_t)cap * kPatch * kPatch * 3));
-    if (w) *w = t;
-    return off;
-}
-static int simil_workspace(sn_ctx *c, int n, SimilWs *w)
-{
-    const int cap = std::min(std::max(n, 8), kSimChunk), npl = simil_mode(c) ? 2 : 1;
-    if (!c->sws || c->sws_n < cap || c->sws_split != npl) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->sws) dev_free_owned(c, c->sws);
-        c->sws = nullptr; c->sws_n = 0;
-        const size_t bytes = simil_carve(c, cap, npl, nullptr);
-        unsigned char *p = nullptr;
-        int rc = dev_alloc(c, &p, bytes);
-        if (rc != SN_OK) return rc;
-        c->sws = p; c->sws_bytes = bytes; c->sws_n = cap; c->sws_split = npl;
-    }
-    simil_carve(c, c->sws_n, npl, w);
-    return SN_OK;
-}
-
-extern "C++" {
-template <int SP>
-static int run_simil_t(sn_ctx *c, const SimilWs &w, int n)
-{
-    int rc;
-    Act cur = w.p0;
-    int cur_cs = 8;
-    int flip[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 13; ++i) {
-        const int st = kSimStage[i], H = kPatch >> st;
-        const bool last = (i == 12 || kSimStage[i + 1] != st);
-        Act out = w.a[st][flip[st]];
-        flip[st] ^= 1;
-        rc = st == 4 ? launch_conv<SCONV5>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n)
-                     : launch_conv<SCONV>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
-        if (rc != SN_OK) return rc;
-        cur = out; cur_cs = kSimC[i + 1];
-        if (last) {
-            const long long total = (long long)(cur_cs / 8) * n * (H / 2) * (H / 2);
-            ProfScope ps(c, "s_pool", 0, (double)total * 16.0 * 5.0 * (SP ? 2 : 1));
-            hipLaunchKernelGGL(maxpool2d_kernel<SP>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, cur.p, w.pool[st].p, H, total,
-                               cur.lo, w.pool[st].lo);
-            HIPCHK(hipGetLastError());
-            cur = w.pool[st];
-        }
-    }
-    {
-        SimilFeatArgs fa;
-        for (int k = 0; k < 5; ++k) { fa.pool[k] = w.pool[k].p; fa.lo_off[k] = w.pool[k].lo; }
-        fa.feat = w.feat; fa.n = n;
-        ProfScope ps(c, "s_features", 0, (double)n * kSimilFeat * (2.0 * (SP ? 2 : 1) + 4.0));
-        hipLaunchKernelGGL(simil_features_kernel<SP>, dim3((unsigned)n), dim3(256), 0, c->stream, fa);
-        HIPCHK(hipGetLastError());
-    }
-    {
-        ProfScope ps(c, "s_dense", 2.0 * n * kSimilFeat * kEmb, (double)n * (kSimilFeat + kEmb) * 4.0 + (double)kSimilFeat * kEmb * 4.0);
-        hipLaunchKernelGGL(simil_dense_kernel, dim3((unsigned)((n + 31) / 32), kDenseKS), dim3(256), 0, c->stream, w.feat, c->semb_W, w.part, n);
-        hipLaunchKernelGGL(simil_dense_reduce_kernel, dim3((unsigned)((n * kEmb + 255) / 256)), dim3(256), 0, c->stream, w.part, c->semb_b, w.emb, n);
-        HIPCHK(hipGetLastError());
-    }
-    return SN_OK;
-}
-}   // extern "C++"
-static int run_simil(sn_ctx *c, const SimilWs &w, int n) { return simil_mode(c) ? run_simil_t<1>(c, w, n) : run_simil_t<0>(c, w, n); }
-
-static int simil_ready(sn_ctx *c)
-{
-    if (!c->simil_loaded) return fail(SN_ERR_STATE, "sn_simil_load_weights has not been called");
-    return simil_pack(c);     // re-packs after a precision switch
-}
-
-static int launch_crop(sn_ctx *c, int view, int n, const double *ch_dev, const double *cw_dev, unsigned char *patches_dev, Act p0,
-                       const float *mean_bgr)
-{
-    const long long total = (long long)n * kPatch * kPatch;
-    const uint8_t *img = c->img_base + c->h_img_off[view];
-    const float mb = mean_bgr ? mean_bgr[0] : 0.f, mg = mean_bgr ? mean_bgr[1] : 0.f, mr = mean_bgr ? mean_bgr[2] : 0.f;
-    const int sp = simil_mode(c);
-    ProfScope ps(c, "patch_crop", 0, (double)total * (3.0 + (patches_dev ? 3.0 : 0.0) + (p0.p ? 16.0 * (sp ? 2 : 1) : 0.0)));
-    if (sp) hipLaunchKernelGGL(patch_crop_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, img, c->h_img_h[view], c->h_img_w[view],
-                               ch_dev, cw_dev, n, patches_dev, p0.p, p0.lo, mb, mg, mr);
-    else hipLaunchKernelGGL(patch_crop_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, img, c->h_img_h[view], c->h_img_w[view],
-                            ch_dev, cw_dev, n, patches_dev, p0.p, p0.lo, mb, mg, mr);
-    HIPCHK(hipGetLastError());
-    return SN_OK;
-}
-
-static int check_view(sn_ctx *c, int view)
-{
-    if (!c->img_base) return fail(SN_ERR_STATE, "sn_set_images must be called first");
-    if (view < 0 || view >= c->V_img) return fail(SN_ERR_ARG, "view %d out of range for %d images", view, c->V_img);
-    return SN_OK;
-}
-
-extern "C" int sn_crop_patches(sn_ctx *c, int view, int n, const double *center_h, const double *center_w, unsigned char *patches)
-{
-    if (!c || !center_h || !center_w || !patches) return fail(SN_ERR_ARG, "null argument");
-    if (n < 0) return fail(SN_ERR_ARG, "bad n");
-    if (n == 0) return SN_OK;
-    HIPCHK(hipSetDevice(c->device));
-    int rc;
-    if ((rc = check_view(c, view)) != SN_OK) return rc;
-    SimilWs w;
-    for (int i0 = 0; i0 < n; i0 += kSimChunk) {
-        const int m = std::min(kSimChunk, n - i0);
-        if ((rc = simil_workspace(c, m, &w)) != SN_OK) return rc;
-        HIPCHK(hipMemcpyAsync(w.centers, center_h + i0, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(w.centers + c->sws_n, center_w + i0, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        if ((rc = launch_crop(c, view, m, w.centers, w.centers + c->sws_n, w.patches, Act{nullptr, 0}, nullptr)) != SN_OK) return rc;
-        HIPCHK(hipMemcpyAsync(patches + (size_t)i0 * kPatch * kPatch * 3, w.patches, (size_t)m * kPatch * kPatch * 3, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    return SN_OK;
-}
-
-extern "C" int sn_patch2embedding(sn_ctx *c, int n, const float *patches, float *embeddings)
-{
-    if (!c || !patches || !embeddings) return fail(SN_ERR_ARG, "null argument");
-    if (n < 0) return fail(SN_ERR_ARG, "bad n");
-    if (n == 0) return SN_OK;
-    HIPCHK(hipSetDevice(c->device));
-    int rc;
-    if ((rc = simil_ready(c)) != SN_OK) return rc;
-    TmpDev t;
-    const size_t per = (size_t)3 * kPatch * kPatch;
-    float *d_x = t.get<float>(per * std::min(n, kSimChunk));
-    if (!d_x) return fail(SN_ERR_NOMEM, "sn_patch2embedding: device allocation failed");
-    SimilWs w;
-    for (int i0 = 0; i0 < n; i0 += kSimChunk) {
-        const int m = std::min(kSimChunk, n - i0);
-        if ((rc = simil_workspace(c, m, &w)) != SN_OK) return rc;
-        HIPCHK(hipMemcpyAsync(d_x, patches + (size_t)i0 * per, sizeof(float) * per * m, hipMemcpyHostToDevice, c->stream));
-        {
-            const long long total = (long long)m * kPatch * kPatch;
-            ProfScope ps(c, "nchw_to_p0", 0, (double)total * (12.0 + 16.0 * (simil_mode(c) ? 2 : 1)));
-            if (simil_mode(c)) hipLaunchKernelGGL(nchw_to_p0_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_x, m, w.p0.p, w.p0.lo);
-            else hipLaunchKernelGGL(nchw_to_p0_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_x, m, w.p0.p, w.p0.lo);
-            HIPCHK(hipGetLastError());
-        }
-        if ((rc = run_simil(c, w, m)) != SN_OK) return rc;
-        HIPCHK(hipMemcpyAsync(embeddings + (size_t)i0 * kEmb, w.emb, sizeof(float) * kEmb * m, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    return SN_OK;
-}
-
-extern "C" int sn_crop_embed(sn_ctx *c, int view, int n, const double *center_h, const double *center_w, const float *mean_bgr, float *embeddings)
-{
-    if (!c || !center_h || !center_w || !mean_bgr || !embeddings) return fail(SN_ERR_ARG, "null argument");
-    if (n < 0) return fail(SN_ERR_ARG, "bad n");
-    if (n == 0) return SN_OK;
-    HIPCHK(hipSetDevice(c->device));
-    int rc;
-    if ((rc = check_view(c, view)) != SN_OK) return rc;
-    if ((rc = simil_ready(c)) != SN_OK) return rc;
-    SimilWs w;
-    for (int i0 = 0; i0 < n; i0 += kSimChunk) {
-        const int m = std::min(kSimChunk, n - i0);
-        if ((rc = simil_workspace(c, m, &w)) != SN_OK) return rc;
-        HIPCHK(hipMemcpyAsync(w.centers, center_h + i0, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(w.centers + c->sws_n, center_w + i0, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        if ((rc = launch_crop(c, view, m, w.centers, w.centers + c->sws_n, nullptr, w.p0, mean_bgr)) != SN_OK) return rc;
-        if ((rc = run_simil(c, w, m)) != SN_OK) return rc;
-        HIPCHK(hipMemcpyAsync(embeddings + (size_t)i0 * kEmb, w.emb, sizeof(float) * kEmb * m, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    return SN_OK;
-}
-
-extern "C" int sn_embeddingpair2simil(sn_ctx *c, int n_pairs, const float *emb_pairs, float *similarity)
-{
-    if (!c || !emb_pairs || !similarity) return fail(SN_ERR_ARG, "null argument");
-    if (n_pairs < 0) return fail(SN_ERR_ARG, "bad n_pairs");
-    if (n_pairs == 0) return SN_OK;
-    if (!c->simil_loaded) return fail(SN_ERR_STATE, "sn_simil_load_weights has not been called");
-    HIPCHK(hipSetDevice(c->device));
-    TmpDev t;
-    float *d_e = t.get<float>((size_t)2 * n_pairs * kEmb), *d_s = t.get<float>(n_pairs);
-    if (!d_e || !d_s) return fail(SN_ERR_NOMEM, "sn_embeddingpair2simil: device allocation failed");
-    HIPCHK(hipMemcpyAsync(d_e, emb_pairs, sizeof(float) * 2 * n_pairs * kEmb, hipMemcpyHostToDevice, c->stream));
-    {
-        ProfScope ps(c, "pair_simil", 0, (double)n_pairs * (2.0 * kEmb + 1.0) * 4.0);
-        hipLaunchKernelGGL(pair_simil_kernel, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, c->stream, d_e, d_s, n_pairs, c->ssim_w, c->ssim_b);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipMemcpyAsync(similarity, d_s, sizeof(float) * n_pairs, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return SN_OK;
 }
 
 // ---- multi-GPU exchange: RCCL all-gather over xGMI (the one collective of the path) ---------------------

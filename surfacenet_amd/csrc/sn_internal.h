@@ -1,0 +1,253 @@
+// sn_internal.h — shared by the translation units of libsurfacenet_hip.so (sn_api.hip: context, weights, hot path,
+// RCCL, profiling; sn_post.hip: ray pooling + dense2sparse; sn_simil.hip: similarityNet + patch cropping): error state,
+// the context, owned device memory, HIP-event profiling, packed conv layers and the launcher of conv3d_f16_mfma.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/surfacenet_hip.h"
+#include "conv3d_mfma.h"
+#include "cvc_warp.h"
+#include "elementwise.h"
+
+using namespace sn;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+inline thread_local std::string g_err;   // one per thread for the whole library (C++17 inline variable)
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(SN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+
+// A conv layer prepared for conv3d_f16_mfma: packed fp16 weight fragments + folded BN.
+struct PackedConv {
+    std::string name;
+    int cin = 0, cout = 0, ks = 1, dil = 1, act = 0;
+    int cin_p = 0;             // input channels padded to 8
+    int nf = 0, nsplit = 1;    // 16-channel fragments per workgroup, workgroup columns
+    int cs8max = 4, split = 0, k2d = 0;   // k2d: ks x ks taps over (y,z) only (2-D nets)
+    std::vector<unsigned char> slab_c8;
+    long long wsplit_stride = 0;   // halfs
+    _Float16 *wpack = nullptr;     // device
+    float *scale = nullptr, *shift = nullptr;  // device, nsplit*nf*16
+    double macs_per_voxel = 0;
+};
+
+struct ProfRec { int tag; hipEvent_t e0, e1; double flops, bytes; };
+struct ProfStat { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
+
+struct sn_ctx {
+    int device = 0, s = 32, max_samples = 0;
+    hipStream_t stream = nullptr;
+    // images / cameras
+    int V_img = 0, V_cam = 0;
+    uint8_t *img_base = nullptr; long long *img_off = nullptr; int *img_h = nullptr, *img_w = nullptr;
+    double *cams = nullptr;
+    // weights
+    bool have_weights = false, have_relw = false;
+    int split = 1;              // 0: f16 operands; 1: f16x3 (hi/lo split operands, fp32-class results) — default; 2: f16m8
+    int mode = 1;               // the SN_PRECISION_* value given to sn_set_precision
+    bool tail_m8 = true;        // f16x3: merge_conv_b (the last 3x3x3 layer) runs its two correction terms on the MX-fp8 MFMA
+    bool ws_ready = false; int ws_split = -1;
+    std::map<std::string, PackedConv> conv;
+    float *w3 = nullptr; float scale3 = 0, shift3 = 0;
+    void *zero_page = nullptr; int num_cus = 256;
+    void *rccl_comm = nullptr; int comm_world = 0, comm_rank = 0;   // RCCL communicator (lazy dlopen of librccl)
+    float *relw_W1 = nullptr, *relw_scale = nullptr, *relw_shift = nullptr, *relw_w2 = nullptr; float relw_b2 = 0;
+    // activation workspace (channels-last fp16)
+    _Float16 *x0 = nullptr, *a1 = nullptr, *b1 = nullptr, *cat = nullptr, *p1 = nullptr, *a2 = nullptr, *b2 = nullptr,
+             *p2 = nullptr, *a3 = nullptr, *b3 = nullptr, *a4 = nullptr, *b4 = nullptr, *s2 = nullptr, *s3 = nullptr,
+             *s4 = nullptr, *ma = nullptr;
+    std::vector<void *> ws_owned;
+    float *unf_ws = nullptr;      // [max_samples][s^3]
+    // batch parameter staging
+    int64_t *d_pairs = nullptr; float *d_xyz = nullptr, *d_resol = nullptr, *d_w = nullptr;
+    // host-API staging
+    float *d_X = nullptr;         // [max_samples][6][s^3] fp32 NCDHW
+    float *d_fused = nullptr;     // [max_samples][s^3]
+    std::vector<long long> h_img_off; std::vector<int> h_img_h, h_img_w;   // host copies (patch cropping addresses one view)
+    // similarityNet (N3)
+    PackedConv sconv[13]; bool simil_loaded = false; int simil_split = -1;
+    float *semb_W = nullptr, *semb_b = nullptr; float ssim_w = 0, ssim_b = 0;
+    std::vector<float> simil_host;   // the 13 conv layers' fp32 parameters, kept to re-pack on a precision switch
+    std::vector<sn_param_desc> simil_descs;
+    void *sws = nullptr; size_t sws_bytes = 0; int sws_n = 0, sws_split = -1;
+    // post-pass (ray pooling / dense2sparse) workspace
+    void *rp_ws = nullptr; size_t rp_ws_bytes = 0; int *d_err = nullptr; int *d_counts = nullptr; int d_counts_cap = 0;
+    std::vector<void *> owned;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<ProfStat> prof_stats;
+    std::map<std::string, int> prof_tags;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+template <typename T>
+static int dev_alloc(sn_ctx *c, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(SN_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    c->owned.push_back(q);
+    *p = static_cast<T *>(q);
+    return SN_OK;
+}
+
+static int dev_free_owned(sn_ctx *c, void *p)
+{
+    if (!p) return SN_OK;
+    auto it = std::find(c->owned.begin(), c->owned.end(), p);
+    if (it != c->owned.end()) c->owned.erase(it);
+    HIPCHK(hipFree(p));
+    return SN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling: every launch goes through prof_begin / prof_end
+// ------------------------------------------------------------------------------------------------
+static hipEvent_t get_event(sn_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    sn_ctx *c; ProfRec r; bool on;
+    ProfScope(sn_ctx *ctx, const std::string &tag, double flops, double bytes) : c(ctx), on(ctx->prof_on)
+    {
+        if (!on) return;
+        auto it = c->prof_tags.find(tag);
+        int id;
+        if (it == c->prof_tags.end()) {
+            id = (int)c->prof_stats.size();
+            c->prof_tags[tag] = id;
+            ProfStat st; st.name = tag;
+            c->prof_stats.push_back(st);
+        } else id = it->second;
+        r.tag = id; r.flops = flops; r.bytes = bytes;
+        r.e0 = get_event(c); r.e1 = get_event(c);
+        (void)hipEventRecord(r.e0, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, c->stream);
+        c->prof_recs.push_back(r);
+    }
+};
+
+static int prof_drain(sn_ctx *c)
+{
+    if (c->prof_recs.empty()) return SN_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof_recs) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        ProfStat &st = c->prof_stats[r.tag];
+        st.ms += ms; st.launches += 1; st.flops += r.flops; st.bytes += r.bytes;
+        c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1);
+    }
+    c->prof_recs.clear();
+    return SN_OK;
+}
+
+// Folds BN, packs the weights of one conv layer into MFMA fragment order (defined in sn_api.hip).
+int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const float *gamma, const float *mean,
+              const float *inv_std, int nf, int nsplit, int cs8max, int split);
+
+static bool shape_is(const sn_param_desc &d, std::initializer_list<int> s)
+{
+    if (d.ndim != (int)s.size()) return false;
+    int i = 0;
+    for (int v : s) if (d.shape[i++] != v) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+// A channels-last fp16 activation tensor: hi plane at p, lo plane (f16x3 mode) at p + lo elements.
+struct Act { _Float16 *p; long long lo; };
+
+template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH, int NW, int PADV, int K2D = 0, int OSPLIT = -1>
+static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act out, int out_cs, int out_coff, int out_cp,
+                       float *out_f32, int B, int D, int DX = 0)
+{
+    using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV, K2D>;
+    if (DX <= 0) DX = D;
+    if ((L.k2d != 0) != (K2D != 0)) return fail(SN_ERR_STATE, "%s: packed for a different tap geometry", L.name.c_str());
+    if (L.nf != NF || L.ks != KS || L.dil != DIL || L.cs8max != C::CS8MAX || L.split != SPLIT)
+        return fail(SN_ERR_STATE, "%s: packed for a different kernel configuration", L.name.c_str());
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = in.p; a.in_lo_off = in.lo; a.out = out.p; a.out_lo_off = out.lo; a.out_f32 = out_f32;
+    a.wpack = L.wpack; a.scale = L.scale; a.shift = L.shift;
+    a.w3 = c->w3; a.scale3 = c->scale3; a.shift3 = c->shift3; a.zero_page = c->zero_page;
+    a.wsplit_stride = L.wsplit_stride;
+    a.in_cs = in_cs; a.out_cs = out_cs; a.out_coff = out_coff; a.out_cp = out_cp;
+    a.D = D; a.DX = DX;
+    a.tiles_x = (DX + C::TX - 1) / C::TX; a.tiles_y = (D + C::TY - 1) / C::TY; a.tiles_z = (D + C::TZ - 1) / C::TZ;
+    a.total_tiles = B * a.tiles_x * a.tiles_y * a.tiles_z;
+    a.act = L.act;
+    a.nslab = (int)L.slab_c8.size();
+    for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
+    const double vox = (double)B * DX * D * D;
+    const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : L.cout));
+    ProfScope ps(c, L.name, 2.0 * L.macs_per_voxel * vox, bytes);
+    // persistent workgroups: one resident set, each walking tiles blockIdx.x, +gridDim.x, ...
+    const int resident = std::max(1, c->num_cus * C::WG_PER_CU / L.nsplit);
+    dim3 grid((unsigned)std::min(a.total_tiles, resident), (unsigned)L.nsplit);
+    {
+        // phase-staggered start (only worthwhile when every workgroup walks many tiles): a quarter of the estimated tile time
+        static const int stag = getenv("SN_STAGGER") ? atoi(getenv("SN_STAGGER")) : 0;
+        const int tiles_per_wg = a.total_tiles / (int)grid.x;
+        if (stag && EPI == EPI_STORE && tiles_per_wg >= 8) {
+            double chunks = 0;
+            for (unsigned char c8n : L.slab_c8) chunks += (C::NTAP * c8n + 3) / 4;
+            const double units = chunks * MF * NF * (SPLIT == 1 ? 3.0 : (SPLIT == 2 ? 2.2 : 1.0));
+            a.stagger_clk = (int)(units * 19.5 * 2.0 * 1.3 / 4.0) * stag;
+        }
+    }
+    hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV, K2D, OSPLIT>), grid, dim3(NW * 64), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return SN_OK;
+}
+
+// Temporary device buffers of the host-array entry points (freed on scope exit).
+struct TmpDev {
+    std::vector<void *> p;
+    ~TmpDev() { for (void *q : p) (void)hipFree(q); }
+    template <typename T> T *get(size_t count) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return static_cast<T *>(q); }
+};
+
