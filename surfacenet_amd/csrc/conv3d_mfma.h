@@ -89,7 +89,7 @@ struct ConvArgs {
     unsigned char slab_c8[kMaxSlab];  // 8-channel groups per slab
 };
 
-enum { EPI_STORE = 0, EPI_FINAL = 1 };
+enum { EPI_STORE = 0, EPI_FINAL = 1, EPI_POOL2D = 2 };   // POOL2D (2-D nets): store epilogue fused with the 2x2 max-pool that follows
 
 __device__ __forceinline__ float sn_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -530,6 +530,53 @@ conv3d_f16_mfma(ConvArgs a)
             for (int m = 0; m < MF; ++m)
 #pragma unroll
                 for (int n = 0; n < NF; ++n) asm volatile("" ::"v"(acc[m][n]));
+        } else if constexpr (EPI == EPI_POOL2D) {
+            // conv + bias + ReLU, then Pool2DLayer(2) in registers: the 2x2 pixel quad of an output lives in lanes {l, l^1} (columns)
+            // x {l, l^8} (rows; l^4 for the 4x4-image fragments). max(split(y)) == split(max(y)) bit for bit because the
+            // hi/lo rounding is monotone, so this equals storing the map and max-pooling the stored values. Output: [c/8][DX][D/2][D/2][8].
+            static_assert(K2D != 0, "EPI_POOL2D is a 2-D epilogue");
+            const int Do = D >> 1;
+            const size_t VOLo = (size_t)DX * Do * Do;
+            constexpr int YX = C::F4 ? 4 : 8;                       // lane distance of the row partner
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                const int gx = x0 + (C::F4 ? wave * MF + m : wave * C::XS + (m >> 2)), gy = y0 + (C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3)), gz = z0 + (C::F4 ? (v & 3) : (v & 7));
+                const bool writer = !(v & 1) && !(v & YX) && gx < DX && gy < D && gz < D;     // D is even: the whole quad is inside
+                const size_t vlin = ((size_t)gx * Do + (gy >> 1)) * Do + (gz >> 1);
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                    half4 h, l;
+                    float lo32[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float y = fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f);
+                        y = fmaxf(y, __shfl_xor(y, 1));
+                        y = fmaxf(y, __shfl_xor(y, YX));
+                        if constexpr (OSPLIT == 1) {
+                            _Float16 hh, ll;
+                            sn_split(y, hh, ll);
+                            h[r] = hh; l[r] = ll;
+                        } else {
+                            h[r] = (_Float16)y;
+                            lo32[r] = (y - (float)h[r]) * 4096.f;
+                        }
+                    }
+                    if (writer && nl < a.out_cp) {
+                        const int ch = a.out_coff + nl;
+                        _Float16 *o = a.out + (size_t)b * VOLo * a.out_cs + ((size_t)(ch >> 3) * VOLo + vlin) * 8 + (ch & 7);
+                        *reinterpret_cast<half4 *>(o) = h;
+                        if constexpr (OSPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
+                        if constexpr (OSPLIT == 2) {
+                            char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.out_lo_off);
+                            *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                            *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                        }
+                    }
+                }
+            }
         } else if constexpr (EPI == EPI_STORE) {
 #pragma unroll
             for (int m = 0; m < MF; ++m) {

@@ -5,7 +5,8 @@
 //                          a 64x64 window of nearest-clamped pixels around the truncated cube-centre projection)
 //                          + image.preprocess_patches (utils/image.py:9-36): RGB -> BGR, - mean_BGR, (h,w,c) -> (c,h,w)
 //   nchw_to_p0_kernel      the same network input from host-preprocessed (n,3,64,64) float32 patches
-//   maxpool2d_kernel       Pool2DLayer(2)                                       nets/similarityNet.py:31-47
+//   (Pool2DLayer(2), nets/similarityNet.py:31-47, is fused into the store epilogue of the conv in front of it:
+//    EPI_POOL2D in conv3d_mfma.h)
 //   simil_features_kernel  FlattenLayer(pool5) ++ CropFeatureMapCenterLayer(pool1..4, r=1) -> L2NormLayer
 //                                                                              nets/similarityNet.py:49-57, nets/layers.py:15-81
 //   simil_dense_kernel     DenseLayer(5888 -> 128, linear)                     nets/similarityNet.py:57
@@ -58,28 +59,6 @@ __global__ void __launch_bounds__(256) nchw_to_p0_kernel(const float *X, int n, 
     const float *s = X + (size_t)i * 3 * hw + pix;
     const float v[8] = {s[0], s[hw], s[2 * hw], 0.f, 0.f, 0.f, 0.f, 0.f};
     sn_store8<SPLIT>(p0 + (size_t)idx * 8, lo_off, v);
-}
-
-// in [C/8][N][H][H][8] -> out [C/8][N][H/2][H/2][8]
-template <int SPLIT>
-__global__ void __launch_bounds__(256) maxpool2d_kernel(const _Float16 *in, _Float16 *out, int H, long long total, long long in_lo_off,
-                                                        long long out_lo_off)
-{
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int Ho = H >> 1;
-    const int w = (int)(idx % Ho), h = (int)((idx / Ho) % Ho);
-    const long long plane = idx / ((long long)Ho * Ho);          // (c8 * N + n)
-    const _Float16 *p = in + ((plane * H + 2 * h) * H + 2 * w) * 8;
-    float m[8], q[8];
-    sn_load8<SPLIT>(p, in_lo_off, m);
-#pragma unroll
-    for (int o = 1; o < 4; ++o) {
-        sn_load8<SPLIT>(p + ((long long)(o >> 1) * H + (o & 1)) * 8, in_lo_off, q);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = q[e] > m[e] ? q[e] : m[e];
-    }
-    sn_store8<SPLIT>(out + idx * 8, out_lo_off, m);
 }
 
 struct SimilFeatArgs {

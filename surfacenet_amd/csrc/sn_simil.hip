@@ -13,6 +13,9 @@ static constexpr int kSimParams = 30, kSimChunk = 2048, kSimNF = 4, kSimCS8 = 2;
 #define SCONV 3, 1, 4, kSimNF, EPI_STORE, SP, kSimCS8, 2, 8, 0, 1
 // the 4x4 maps of conv5_x: one MFMA voxel fragment = one image (K2D = 2), 16 images x 128 output channels per workgroup
 #define SCONV5 3, 1, 2, 8, EPI_STORE, SP, kSimCS8, 2, 8, 0, 2
+// the last conv of every block writes the 2x2 max-pooled map directly (EPI_POOL2D): the unpooled map is never stored
+#define SCONVP 3, 1, 4, kSimNF, EPI_POOL2D, SP, kSimCS8, 2, 8, 0, 1
+#define SCONV5P 3, 1, 2, 8, EPI_POOL2D, SP, kSimCS8, 2, 8, 0, 2
 static int simil_nf(int i) { return kSimStage[i] == 4 ? 8 : kSimNF; }
 
 static int simil_mode(sn_ctx *c) { return c->split == 0 ? 0 : 1; }   // f16m8 contexts run this net in f16x3 (own workspace)
@@ -124,20 +127,20 @@ static int run_simil_t(sn_ctx *c, const SimilWs &w, int n)
     for (int i = 0; i < 13; ++i) {
         const int st = kSimStage[i], H = kPatch >> st;
         const bool last = (i == 12 || kSimStage[i + 1] != st);
+        if (last) {      // conv + bias + ReLU + Pool2DLayer(2) in one kernel
+            Act out = w.pool[st];
+            rc = st == 4 ? launch_conv<SCONV5P>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n)
+                         : launch_conv<SCONVP>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
+            if (rc != SN_OK) return rc;
+            cur = out; cur_cs = kSimC[i + 1];
+            continue;
+        }
         Act out = w.a[st][flip[st]];
         flip[st] ^= 1;
         rc = st == 4 ? launch_conv<SCONV5>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n)
                      : launch_conv<SCONV>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
         if (rc != SN_OK) return rc;
         cur = out; cur_cs = kSimC[i + 1];
-        if (last) {
-            const long long total = (long long)(cur_cs / 8) * n * (H / 2) * (H / 2);
-            ProfScope ps(c, "s_pool", 0, (double)total * 16.0 * 5.0 * (SP ? 2 : 1));
-            hipLaunchKernelGGL(maxpool2d_kernel<SP>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, cur.p, w.pool[st].p, H, total,
-                               cur.lo, w.pool[st].lo);
-            HIPCHK(hipGetLastError());
-            cur = w.pool[st];
-        }
     }
     {
         SimilFeatArgs fa;
