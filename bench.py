@@ -38,7 +38,7 @@ def cpu_baseline(scene, values, s, n_vp):
     """Times the oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
     import torch
     from oracle import cvc_oracle, net_oracle
-    n_cvc, n_cnn = 16, 2
+    n_cvc, n_cnn = 64, 32          # ~10 s of host work in total
     sub = lambda k: {kk: (v[:k] if kk in ("xyz", "resol", "pairs", "w") else v) for kk, v in scene.items()}
     a = sub(n_cvc)
     t0 = time.time()

@@ -184,6 +184,10 @@ int sn_crop_embed(sn_ctx *ctx, int view, int n, const double *center_h, const do
 /* embeddingPair2simil_fn (nets/similarityNet.py:223-226): rows 2i, 2i+1 of emb_pairs (2*n_pairs,128) -> (n_pairs,1)
  * sigmoid(w * ||e1 - e2||_2 + b). */
 int sn_embeddingpair2simil(sn_ctx *ctx, int n_pairs, const float *emb_pairs, float *similarity);
+/* earlyRejection.embeddingPairs2simil (utils/earlyRejection.py:59-90) in one call: embeddings (n_cubes, n_views, 128) ->
+ * similarity (n_cubes, n_views*(n_views-1)/2), pairs in itertools.combinations order; bit-identical to feeding the same pairs
+ * through sn_embeddingpair2simil, without shipping every embedding once per pair across PCIe. */
+int sn_embeddings2simil(sn_ctx *ctx, int n_cubes, int n_views, const float *embeddings, float *similarity);
 
 /* ---- multi-GPU (one process per GPU): the path's only exchange is an all-gather of the per-cube fused probabilities
  * (the reference is single-GPU, no counterpart). RCCL over xGMI; librccl is dlopen'ed on first use.

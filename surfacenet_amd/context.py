@@ -195,6 +195,15 @@ class Context(object):
         _lib.check(self._lib.sn_embeddingpair2simil(self._h, e.shape[0] // 2, _lib.ptr(e), _lib.ptr(out)))
         return out
 
+    def embeddings2simil(self, embeddings):
+        """(n_cubes, n_views, 128) float32 -> (n_cubes, n_views*(n_views-1)/2) float32, all 2-combinations of views."""
+        e = np.ascontiguousarray(embeddings, dtype=np.float32)
+        if e.ndim != 3 or e.shape[2] != _weights.D_EMBEDDING or e.shape[1] < 2:
+            raise TypeError("embeddings must have shape (n_cubes, n_views >= 2, %d)" % _weights.D_EMBEDDING)
+        out = np.empty((e.shape[0], e.shape[1] * (e.shape[1] - 1) // 2), dtype=np.float32)
+        _lib.check(self._lib.sn_embeddings2simil(self._h, e.shape[0], e.shape[1], _lib.ptr(e), _lib.ptr(out)))
+        return out
+
     # ---- post-pass (SURVEY §8f row N2) ----------------------------------------------------------------
     def ray_pool(self, selected_viewPairs, xyz, resol, prediction, prediction_thresh=None):
         """rayPooling.rayPooling_1cube_numpy (utils/rayPooling.py:143-260) for n cubes: prediction (n,s,s,s) (or

@@ -165,4 +165,22 @@ __global__ void __launch_bounds__(256) pair_simil_kernel(const float *emb_pairs,
     if (lane == 0) simil[i] = 1.0f / (1.0f + expf(-(w * sqrtf(ss) + b)));
 }
 
+// All 2-combinations of views at once (earlyRejection.embeddingPairs2simil, utils/earlyRejection.py:59-90): emb (n_cubes, n_views,
+// 128), pairs (P,2) -> simil (n_cubes, P). One wave per (cube, pair); same summation order as pair_simil_kernel, so the two
+// entry points agree bit for bit.
+__global__ void __launch_bounds__(256) pair_simil_all_kernel(const float *emb, const int *pairs, float *simil, long long total, int n_views, int P,
+                                                             float w, float b)
+{
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= total) return;
+    const long long cube = i / P;
+    const int p = (int)(i - cube * P);
+    const float *e1 = emb + ((size_t)cube * n_views + pairs[2 * p]) * kEmb, *e2 = emb + ((size_t)cube * n_views + pairs[2 * p + 1]) * kEmb;
+    float ss = 0.f;
+    for (int k = lane; k < kEmb; k += 64) { const float d = fabsf(e1[k] - e2[k]); ss += d * d; }
+    for (int o = 32; o; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) simil[i] = 1.0f / (1.0f + expf(-(w * sqrtf(ss) + b)));
+}
+
 }  // namespace sn

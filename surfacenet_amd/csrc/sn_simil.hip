@@ -285,3 +285,33 @@ extern "C" int sn_embeddingpair2simil(sn_ctx *c, int n_pairs, const float *emb_p
     HIPCHK(hipStreamSynchronize(c->stream));
     return SN_OK;
 }
+
+extern "C" int sn_embeddings2simil(sn_ctx *c, int n_cubes, int n_views, const float *embeddings, float *similarity)
+{
+    if (!c || !embeddings || !similarity) return fail(SN_ERR_ARG, "null argument");
+    if (n_cubes < 0 || n_views < 2) return fail(SN_ERR_ARG, "need n_cubes >= 0 and n_views >= 2");
+    if (n_cubes == 0) return SN_OK;
+    if (!c->simil_loaded) return fail(SN_ERR_STATE, "sn_simil_load_weights has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    const int P = n_views * (n_views - 1) / 2;
+    std::vector<int> pairs;
+    pairs.reserve(2 * (size_t)P);
+    for (int i = 0; i < n_views; ++i)
+        for (int j = i + 1; j < n_views; ++j) { pairs.push_back(i); pairs.push_back(j); }      // itertools.combinations order
+    TmpDev t;
+    const size_t ne = (size_t)n_cubes * n_views * kEmb, ns = (size_t)n_cubes * P;
+    float *d_e = t.get<float>(ne), *d_s = t.get<float>(ns);
+    int *d_p = t.get<int>(pairs.size());
+    if (!d_e || !d_s || !d_p) return fail(SN_ERR_NOMEM, "sn_embeddings2simil: device allocation failed");
+    HIPCHK(hipMemcpyAsync(d_e, embeddings, sizeof(float) * ne, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_p, pairs.data(), sizeof(int) * pairs.size(), hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, "pair_simil_all", 0, (double)ns * (2.0 * kEmb + 1.0) * 4.0);
+        hipLaunchKernelGGL(pair_simil_all_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, c->stream, d_e, d_p, d_s, (long long)ns, n_views, P,
+                           c->ssim_w, c->ssim_b);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(similarity, d_s, sizeof(float) * ns, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}

@@ -54,6 +54,9 @@ def embeddingPairs2simil(embeddings, N_views, inScope_cubes_vs_views, embeddingP
     (the `viewPairs` argument is recomputed, as in the reference: utils/earlyRejection.py:74)."""
     viewPairs = k_combination_np(range(N_views), k=2)
     N_viewPairs, N_cubes = viewPairs.shape[0], embeddings.shape[0]
+    if getattr(embeddingPair2simil_fn, "sn_gpu", False) and embeddings.shape[1] == N_views:
+        # one upload of the embeddings, every 2-combination on the GPU (bit-identical to the batched protocol below)
+        return runtime.any_context().embeddings2simil(embeddings)
     # rows (cube i, view j) in cube-major, pair-major, (first, second) order == the reference's yield_batch_ij_npBool walk
     ii = np.repeat(np.arange(N_cubes), 2 * N_viewPairs)
     jj = np.tile(viewPairs.flatten(), N_cubes)

@@ -31,4 +31,5 @@ def similarityNet_inference(model_file, imgPatch_hw_size=(64, 64), param_values=
         return runtime.any_context().embeddingpair2simil(embeddingPair)
 
     patch2embedding_fn.sn_gpu = True       # lets earlyRejection.patch2embedding fuse crop + preprocess + embedding in HBM
+    embeddingPair2simil_fn.sn_gpu = True   # lets earlyRejection.embeddingPairs2simil evaluate every pair in one call
     return patch2embedding_fn, embeddingPair2simil_fn

@@ -123,6 +123,10 @@ def test_early_rejection_dropin_fused_equals_three_step_protocol(sn):
     pairs = k_combination_np(range(N_views), k=2)
     want = simil_oracle.pair_similarity(emb_f[:, pairs.flatten()].reshape(-1, 128), values).reshape(N_cubes, -1)
     assert dis.shape == (N_cubes, 3) and np.abs(dis - want).max() < 1e-6
+    # the one-call all-pairs path (taken above because pair_fn is GPU-backed) == the reference's batched pair protocol
+    dis_b = earlyRejection.embeddingPairs2simil(embeddings=emb_f, embeddingPair2simil_fn=lambda e: pair_fn(e), inScope_cubes_vs_views=ins_f,
+                                                viewPairs=pairs, N_views=N_views, batchSize=4)
+    assert np.array_equal(dis, dis_b)
     with pytest.raises(TypeError):
         p2e(np.zeros((1, 3, 64, 64)))                              # float64, as Theano would reject
     with pytest.raises(NotImplementedError):
