@@ -103,6 +103,13 @@ int sn_cvc_forward(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, cons
  * features (n*n_vp, 258) float32 -> softmax weights (n, n_vp). */
 int sn_relative_weights(sn_ctx *ctx, int n, int n_vp, const float *features, float *weights);
 
+/* The weight computation of viewPairSelection.viewPairSelection (utils/viewPairSelection.py:63-77) for every 2-combination of
+ * views (itertools.combinations order) in one call: embeddings (n_cubes,n_views,128), dissimilarity and theta (n_cubes,P)
+ * float32 -> softmax weights (n_cubes,P). Bit-identical to building the (n_cubes*P,258) feature rows and calling
+ * sn_relative_weights with n_vp = P. */
+int sn_viewpair_weights(sn_ctx *ctx, int n_cubes, int n_views, const float *embeddings, const float *dissimilarity,
+                        const float *theta, float *weights);
+
 /* utils.generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42; call at main_reconstruct.py:150-152), float32 op for
  * op: cvc (n*n_vp,6,s,s,s) is the MEAN-SUBTRACTED tensor of sn_cvc_forward (the caller's `X += mean` is applied inside);
  * unfused (n,n_vp,s,s,s), w (n,n_vp) -> rgb (n,3,s,s,s) uint8. */

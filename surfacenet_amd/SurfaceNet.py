@@ -50,4 +50,6 @@ def SurfaceNet_inference(N_viewPairs4inference, model_file, layerNameList_2_load
             return [fused, fused]      # both outputs are the same tensor in the reference (SurfaceNet.py:355-357)
         return [fused, unfused]
 
+    viewPair_relativeImpt_fn.sn_gpu = True     # lets viewPairSelection.viewPairSelection skip the (N*P, 258) feature matrix
+    viewPair_relativeImpt_fn.sn_cube_D = cube_D
     return viewPair_relativeImpt_fn, nViewPair_SurfaceNet_fn

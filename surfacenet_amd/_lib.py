@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SURFACENET_HIP_LIB") or os.path.join(_HERE, "libsurfa
 ABI_SYMBOLS = [
     "sn_create", "sn_destroy", "sn_last_error", "sn_version", "sn_synchronize", "sn_set_precision", "sn_get_precision", "sn_stream",
     "sn_load_weights", "sn_set_images", "sn_set_cameras",
-    "sn_cvc", "sn_forward", "sn_cvc_forward", "sn_relative_weights", "sn_color_fuse", "sn_color_fuse_dev",
+    "sn_cvc", "sn_forward", "sn_cvc_forward", "sn_relative_weights", "sn_viewpair_weights", "sn_color_fuse", "sn_color_fuse_dev",
     "sn_dev_alloc", "sn_dev_free", "sn_memcpy_h2d", "sn_memcpy_d2h",
     "sn_cvc_forward_dev", "sn_cvc_dev", "sn_forward_dev",
     "sn_ray_pool", "sn_ray_pool_dev", "sn_dense2sparse", "sn_dense2sparse_dev",
@@ -72,6 +72,7 @@ def load():
         "sn_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
         "sn_cvc_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 8),
         "sn_relative_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+        "sn_viewpair_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
         "sn_color_fuse": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5),
         "sn_color_fuse_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5),
         "sn_dev_alloc": (c_void_p, [c_void_p, c_size_t]),

@@ -139,6 +139,17 @@ class Context(object):
         _lib.check(self._lib.sn_relative_weights(self._h, n, n_vp, _lib.ptr(f), _lib.ptr(out)))
         return out
 
+    def viewpair_weights(self, embeddings, dissimilarity, theta):
+        """(n_cubes,n_views,128), (n_cubes,P), (n_cubes,P) float32 -> (n_cubes,P) softmax weights over all 2-combinations."""
+        e = np.ascontiguousarray(embeddings, dtype=np.float32)
+        n, V = e.shape[:2]
+        P = V * (V - 1) // 2
+        d = np.ascontiguousarray(dissimilarity, dtype=np.float32).reshape(n, P)
+        t = np.ascontiguousarray(theta, dtype=np.float32).reshape(n, P)
+        out = np.empty((n, P), dtype=np.float32)
+        _lib.check(self._lib.sn_viewpair_weights(self._h, n, V, _lib.ptr(e), _lib.ptr(d), _lib.ptr(t), _lib.ptr(out)))
+        return out
+
     def color_fuse(self, cvc_minus_mean, unfused, w, mean=MEAN_CVC_RGBRGB):
         """utils.generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42): (n,3,s,s,s) uint8 fused colours from the
         mean-subtracted CVC tensor (n*n_vp,6,s,s,s), the unfused predictions (n,n_vp,s,s,s) and the pair weights (n,n_vp)."""

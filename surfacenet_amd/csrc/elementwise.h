@@ -228,6 +228,39 @@ static __global__ void __launch_bounds__(128) relw_mlp_kernel(const float *feat,
     if (j == 0) z[row] = red[0] + b2;
 }
 
+// Same MLP with the feature row assembled on the fly (utils/viewPairSelection.py:69-74): row (cube, pair p = (i,j)) =
+// [emb[cube,i] (128) | emb[cube,j] (128) | dissimilarity[cube,p] | angle[cube,p]]; same accumulation order as relw_mlp_kernel,
+// so the two agree bit for bit. emb (n_cubes, n_views, 128); pairs (P,2); d, theta (n_cubes, P).
+static __global__ void __launch_bounds__(128) relw_mlp_pairs_kernel(const float *emb, const int *pairs, const float *d, const float *theta, int n_views,
+                                                             int P, const float *W1, const float *scale1, const float *shift1, const float *w2,
+                                                             float b2, float *z, int n_hidden)
+{
+    __shared__ float red[128];
+    __shared__ float f[258];
+    const long long row = blockIdx.x;
+    const int j = threadIdx.x;
+    const long long cube = row / P;
+    const int p = (int)(row - cube * P);
+    const float *e1 = emb + ((size_t)cube * n_views + pairs[2 * p]) * 128, *e2 = emb + ((size_t)cube * n_views + pairs[2 * p + 1]) * 128;
+    f[j] = e1[j];
+    f[128 + j] = e2[j];
+    if (j == 0) { f[256] = d[row]; f[257] = theta[row]; }
+    __syncthreads();
+    float hv = 0.f;
+    if (j < n_hidden) {
+        float acc = 0.f;
+        for (int k = 0; k < 258; ++k) acc += f[k] * W1[(size_t)k * n_hidden + j];
+        hv = 1.0f / (1.0f + expf(-(acc * scale1[j] + shift1[j]))) * w2[j];
+    }
+    red[j] = hv;
+    __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) {
+        if (j < st) red[j] += red[j + st];
+        __syncthreads();
+    }
+    if (j == 0) z[row] = red[0] + b2;
+}
+
 static __global__ void relw_softmax_kernel(const float *z, float *out, int n, int n_vp)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;

@@ -720,6 +720,42 @@ int sn_relative_weights(sn_ctx *c, int n, int n_vp, const float *features, float
     return SN_OK;
 }
 
+// viewPairSelection's weight computation for EVERY 2-combination of views at once (utils/viewPairSelection.py:63-77): the
+// (n_cubes*P, 258) feature matrix is never materialised, embeddings cross PCIe once.
+int sn_viewpair_weights(sn_ctx *c, int n_cubes, int n_views, const float *embeddings, const float *dissimilarity, const float *theta,
+                        float *weights)
+{
+    if (!c || !embeddings || !dissimilarity || !theta || !weights) return fail(SN_ERR_ARG, "null argument");
+    if (n_cubes < 0 || n_views < 2) return fail(SN_ERR_ARG, "need n_cubes >= 0 and n_views >= 2");
+    if (n_cubes == 0) return SN_OK;
+    if (!c->have_relw) return fail(SN_ERR_STATE, "the relative-weight MLP arrays (params 98..104) were not loaded");
+    if (kDFeature != 258 || kHidden > 128) return fail(SN_ERR_STATE, "unexpected MLP geometry");
+    HIPCHK(hipSetDevice(c->device));
+    const int P = n_views * (n_views - 1) / 2;
+    std::vector<int> pairs;
+    for (int i = 0; i < n_views; ++i)
+        for (int j = i + 1; j < n_views; ++j) { pairs.push_back(i); pairs.push_back(j); }
+    const size_t rows = (size_t)n_cubes * P, ne = (size_t)n_cubes * n_views * 128;
+    TmpDev t;
+    float *d_e = t.get<float>(ne), *d_d = t.get<float>(rows), *d_t = t.get<float>(rows), *d_z = t.get<float>(rows), *d_o = t.get<float>(rows);
+    int *d_p = t.get<int>(pairs.size());
+    if (!d_e || !d_d || !d_t || !d_z || !d_o || !d_p) return fail(SN_ERR_NOMEM, "sn_viewpair_weights: device allocation failed");
+    HIPCHK(hipMemcpyAsync(d_e, embeddings, sizeof(float) * ne, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_d, dissimilarity, sizeof(float) * rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_t, theta, sizeof(float) * rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_p, pairs.data(), sizeof(int) * pairs.size(), hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, "relw_mlp_pairs", 2.0 * rows * kDFeature * kHidden, (double)rows * 12.0 + (double)ne * 4.0);
+        hipLaunchKernelGGL(relw_mlp_pairs_kernel, dim3((unsigned)rows), dim3(128), 0, c->stream, d_e, d_p, d_d, d_t, n_views, P, c->relw_W1, c->relw_scale,
+                           c->relw_shift, c->relw_w2, c->relw_b2, d_z, kHidden);
+        hipLaunchKernelGGL(relw_softmax_kernel, dim3((unsigned)((n_cubes + 127) / 128)), dim3(128), 0, c->stream, d_z, d_o, n_cubes, P);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(weights, d_o, sizeof(float) * rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
 // utils.generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42) on device-resident tensors
 int sn_color_fuse_dev(sn_ctx *c, int n, int n_vp, const float *cvc_dev, const float *mean6, const float *unfused_dev,
                       const float *w_dev, unsigned char *rgb_dev)

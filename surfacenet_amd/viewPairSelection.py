@@ -71,6 +71,14 @@ def viewPairSelection(cameraTs_np, e_viewPairs, d_viewPairs, validCubes, cubeCen
     d = d_viewPairs[validCubes][..., None]
     e_valid = e_viewPairs[validCubes]
     w_viewPairs = np.empty((N_validCubes, N_viewPairs), dtype=np.float32)
+    N_views = e_viewPairs.shape[1]
+    if getattr(viewPair_relativeImpt_fn, "sn_gpu", False) and N_validCubes and viewPairs.shape == (N_views * (N_views - 1) // 2, 2) \
+            and np.array_equal(viewPairs, k_combination_np(range(N_views), k=2)):
+        # all 2-combinations in combinations order: the GPU assembles the feature rows itself (bit-identical to the loop below)
+        from . import runtime
+        ctx = runtime.context_for(viewPair_relativeImpt_fn.sn_cube_D)
+        w_viewPairs = ctx.viewpair_weights(e_valid, d[..., 0].astype(np.float32), theta[..., 0].astype(np.float32))
+        return __argmaxN_viewPairs__(viewPairs=viewPairs, w_viewPairs=w_viewPairs, N_argmax=N_viewPairs4inference)
     for _batch in yield_batch_npBool(N_all=N_validCubes, batch_size=int(math.floor(float(batchSize) / N_viewPairs))):
         N_batch = int(_batch.sum())
         e = e_valid[_batch][:, viewPairs.flatten()].reshape((N_batch, N_viewPairs, 2 * D_embedding))

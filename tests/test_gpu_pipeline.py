@@ -48,11 +48,12 @@ def test_reconstruct_scene_equals_reference_style_script(gpu_required):
     plain_p2e = lambda x: p2e(x)                                            # three-step crop / preprocess / embed protocol
     emb, inscope = earlyRejection.patch2embedding(imgs, ih, iw, plain_p2e, MEAN_BGR, N_cubes, 4, 128, patchSize=64, batchSize=5,
                                                   cubeCenter_hw=np.stack([ch, cw], axis=0))
-    dis = earlyRejection.embeddingPairs2simil(embeddings=emb, embeddingPair2simil_fn=pair_fn, inScope_cubes_vs_views=inscope, viewPairs=viewPairs,
+    dis = earlyRejection.embeddingPairs2simil(embeddings=emb, embeddingPair2simil_fn=lambda e: pair_fn(e), inScope_cubes_vs_views=inscope, viewPairs=viewPairs,
                                               N_views=4, batchSize=7)
     valid = earlyRejection.selectFromSimilarity(dis, N_vp)
     assert 0 < valid.sum() < N_cubes and not valid[5], np.round(dis, 3)    # the early rejection really rejects something
-    vp, w = viewPairSelection.viewPairSelection(cameraTs, emb, dis, valid, cubes["xyz"] + cube_D_mm / 2., relw_fn, 13, N_vp, viewPairs)
+    plain_relw = lambda f, n_samples_perGroup: relw_fn(f, n_samples_perGroup)      # explicit (N*P, 258) feature rows, batched
+    vp, w = viewPairSelection.viewPairSelection(cameraTs, emb, dis, valid, cubes["xyz"] + cube_D_mm / 2., plain_relw, 13, N_vp, viewPairs)
     lists = ([], [], [], [], None, None, None)
     p_l, rgb_l, ijk_l, v_l, cube_ijk, param_np, vp_np = lists
     for _batch in reconstruct.gen_non0Batch_npBool(valid, 4):
