@@ -197,3 +197,36 @@ def test_sparse_loop_device_chain_equals_piecewise(sn, n_vp, crop):
     assert np.array_equal(got[5], want[5])
     assert got2[0] == [i for i in want[0] if i < 2]
     assert all(np.array_equal(a, b) for a, b in zip(got2[1], want[1]))
+
+
+def test_empty_batches_everywhere(sn):
+    """n = 0 through every host-array entry point: empty results of the right shape and dtype, no error (the reference's
+    numpy code returns empty arrays in the same situations)."""
+    import synth
+    from surfacenet_amd import weights
+    s = 8
+    z = lambda *sh, dt=np.float32: np.zeros(sh, dtype=dt)
+    with sn.Context(cube_D=s, max_samples=4) as ctx:
+        ctx.load_param_values(list(synth.calibrated_params(0)))
+        ctx.load_simil_param_values(weights.synthetic_simil_param_values(0))
+        ctx.set_cameras(P_DTU)
+        ctx.set_images([np.zeros((40, 50, 3), np.uint8)] * 4)
+        pairs0, xyz0, r0 = z(0, 2, 2, dt=np.int64), z(0, 3), z(0)
+        assert ctx.cvc(pairs0, xyz0, r0).shape == (0, 6, s, s, s)
+        f, u = ctx.forward(z(0, 6, s, s, s), z(0, 2), n_vp=2)
+        assert f.shape == (0, 1, s, s, s) and u.shape == (0, 2, s, s, s)
+        f, u, c = ctx.cvc_forward(pairs0, xyz0, r0, z(0, 2), return_cvc=True)
+        assert f.shape == (0, 1, s, s, s) and c.shape == (0, 6, s, s, s)
+        assert ctx.relative_weights(z(0, 258), 3).shape == (0, 3)
+        assert ctx.color_fuse(z(0, 6, s, s, s), z(0, 2, s, s, s), z(0, 2)).shape == (0, 3, s, s, s)
+        assert ctx.ray_pool(pairs0, xyz0, r0, z(0, s, s, s), 0.5).shape == (0, s, s, s)
+        off, ijk, p16, rgb, votes = ctx.dense2sparse(z(0, s, s, s), z(0, 3, s, s, s, dt=np.uint8), pairs0, xyz0, r0, enable_rayPooling=True)
+        assert off.tolist() == [0] and ijk.shape == (0, 3) and p16.dtype == np.float16 and votes.shape == (0,)
+        assert ctx.crop_patches(0, z(0, dt=np.float64), z(0, dt=np.float64)).shape == (0, 64, 64, 3)
+        assert ctx.patch2embedding(z(0, 3, 64, 64)).shape == (0, 128)
+        assert ctx.crop_embed(1, z(0, dt=np.float64), z(0, dt=np.float64), [1, 2, 3]).shape == (0, 128)
+        assert ctx.embeddingpair2simil(z(0, 128)).shape == (0, 1)
+        assert ctx.embeddings2simil(z(0, 4, 128)).shape == (0, 6)
+        assert ctx.viewpair_weights(z(0, 4, 128), z(0, 6), z(0, 6)).shape == (0, 6)
+        # and the context still works afterwards
+        assert ctx.ray_pool(np.zeros((1, 1, 2), int), np.asarray([[0, 0, 600.0]]), np.full(1, 0.4), field(3, 8, 1), 0.5).shape == (1, s, s, s)
