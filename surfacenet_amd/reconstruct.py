@@ -133,6 +133,75 @@ class SparseLoop(object):
         return nonempty, cut(ijk), cut(p16), cut(rgb), (cut(votes) if votes is not None else []), xyz_new
 
 
+    def run_many(self, viewPairs, xyz, resol, w=None):
+        """The same for ANY number of cubes, software-pipelined over batches of `max_cubes`: all cube parameters go up in
+        one piece, the kernels of batch i+1 are enqueued before the sparse lists of batch i are fetched (double-buffered
+        outputs), so the GPU idles only for the few small D2H copies per batch. Same return value as `run`."""
+        ctx, d, n_vp, B = self.ctx, self.d, self.n_vp, self.max_cubes
+        pairs = np.ascontiguousarray(viewPairs, dtype=np.int64)
+        n = pairs.shape[0]
+        if pairs.shape[1:] != (n_vp, 2):
+            raise ValueError("viewPairs must have shape (n, %d, 2)" % n_vp)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(n, 3)
+        resol = np.ascontiguousarray(resol, dtype=np.float32).reshape(n)
+        xyz_new = xyz + (resol[:, None] * self.lo).astype(np.float32) if self.cfg["enable_centerCrop"] else xyz.copy()
+        out = ([], [], [], [], [], xyz_new)
+        if n == 0:
+            return out
+        V = ctx.n_views
+        if pairs.max() >= V or pairs.min() < -V:
+            raise IndexError("view index out of range for %d views" % V)
+        pairs = np.where(pairs < 0, pairs + V, pairs)
+        w = np.full((n, n_vp), 1.0 / n_vp, np.float32) if w is None else np.ascontiguousarray(w, dtype=np.float32).reshape(n, n_vp)
+        votes_on = bool(self.cfg["enable_rayPooling"])
+        if "ijk2" not in d:          # second set of output buffers
+            cap = B * self.dc ** 3
+            d.update(offsets2=ctx.dev_alloc((B + 1) * 8), ijk2=ctx.dev_alloc(cap * 3), p162=ctx.dev_alloc(cap * 2), rgb_out2=ctx.dev_alloc(cap * 3),
+                     votes_out2=ctx.dev_alloc(cap))
+        outs = [dict(offsets=d["offsets"], ijk=d["ijk"], p16=d["p16"], rgb_out=d["rgb_out"], votes_out=d["votes_out"]),
+                dict(offsets=d["offsets2"], ijk=d["ijk2"], p16=d["p162"], rgb_out=d["rgb_out2"], votes_out=d["votes_out2"])]
+        gp, gx, gr, gw = ctx.upload(pairs), ctx.upload(xyz), ctx.upload(resol), ctx.upload(w)
+        try:
+            def enqueue(i0, o):
+                m = min(B, n - i0)
+                pp, px, pr, pw = gp + i0 * n_vp * 16, gx + i0 * 12, gr + i0 * 4, gw + i0 * n_vp * 4
+                ctx.cvc_forward_dev(m, n_vp, pp, px, pr, pw, d["fused"], d["unfused"], d["cvc"], mean=self.mean)
+                ctx.color_fuse_dev(m, n_vp, d["cvc"], d["unfused"], pw, d["rgb"], mean=self.mean)
+                ctx.dense2sparse_dev(m, n_vp, pp, px, pr, d["fused"], d["rgb"], d["votes"], o["offsets"], o["ijk"], o["p16"], o["rgb_out"],
+                                     o["votes_out"], **self.cfg)
+                return m
+
+            def fetch(i0, m, o):
+                off = np.zeros((m + 1,), dtype=np.int64)
+                ctx.d2h(off, o["offsets"])
+                T = int(off[-1])
+                ijk = np.empty((T, 3), np.uint8); p16 = np.empty((T,), np.float16); rgb = np.empty((T, 3), np.uint8)
+                votes = np.empty((T,), np.uint8) if votes_on else None
+                if T:
+                    ctx.d2h(ijk, o["ijk"]); ctx.d2h(p16, o["p16"]); ctx.d2h(rgb, o["rgb_out"])
+                    if votes_on:
+                        ctx.d2h(votes, o["votes_out"])
+                for i in np.nonzero(np.diff(off))[0]:
+                    a, b = off[i], off[i + 1]
+                    out[0].append(int(i0 + i)); out[1].append(ijk[a:b]); out[2].append(p16[a:b]); out[3].append(rgb[a:b])
+                    if votes_on:
+                        out[4].append(votes[a:b])
+
+            starts = list(range(0, n, B))
+            pending = None
+            for k, i0 in enumerate(starts):
+                m = enqueue(i0, outs[k & 1])
+                if pending is not None:
+                    fetch(*pending)              # blocks until batch k's kernels (enqueued above) have drained, i.e. the GPU stays busy
+                pending = (i0, m, outs[k & 1])
+            fetch(*pending)
+            ctx.synchronize()                    # surfaces the ray-pooling range error, if any
+        finally:
+            for p in (gp, gx, gr, gw):
+                ctx.dev_free(p)
+        return out
+
+
 def shard_bounds(n, world, rank):
     """Contiguous range [lo, hi) of rank's cubes: ceil(n/world) per rank, the tail ranks may be short or empty."""
     per = -(-int(n) // int(world))
@@ -256,22 +325,15 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
     loop = SparseLoop(ctx, N_vp, max_cubes=bs, min_prob=min_prob, rayPool_thresh=0, enable_centerCrop=True, cube_Dcenter=cube_Dcenter,
                       enable_rayPooling=True)
     try:
-        for _batch in gen_non0Batch_npBool(validCubes, bs):
-            sel = _batch[validCubes]
-            nonempty, ijk_l, p_l, rgb_l, v_l, xyz_new = loop.run(viewPairs4Reconstr[sel], cubes_param_np['xyz'][_batch], cubes_param_np['resol'][_batch],
-                                                                 w_viewPairs4Reconstr[sel])
-            param_sub = np.copy(cubes_param_np[_batch])
-            param_sub['xyz'] = xyz_new
-            param_sub = param_sub[nonempty]
-            vp_sub = viewPairs4Reconstr[sel].astype(np.uint16)[nonempty]
-            ijk_sub = cubes_param_np['ijk'][_batch][nonempty]
-            out["prediction_list"].extend(p_l); out["rgb_list"].extend(rgb_l); out["vxl_ijk_list"].extend(ijk_l)
-            out["rayPooling_votes_list"].extend(v_l)
-            out["param_np"] = param_sub if out["param_np"] is None else np.concatenate([out["param_np"], param_sub], axis=0)
-            out["viewPair_np"] = vp_sub if out["viewPair_np"] is None else np.vstack([out["viewPair_np"], vp_sub])
-            out["cube_ijk_np"] = ijk_sub if out["cube_ijk_np"] is None else np.vstack([out["cube_ijk_np"], ijk_sub])
+        # the batches of gen_non0Batch_npBool(validCubes, bs) are consecutive runs of valid cubes: run_many walks exactly those
+        nonempty, ijk_l, p_l, rgb_l, v_l, xyz_new = loop.run_many(viewPairs4Reconstr, cubes_param_np['xyz'][validCubes],
+                                                                  cubes_param_np['resol'][validCubes], w_viewPairs4Reconstr)
     finally:
         loop.close()
+    param_sub = np.copy(cubes_param_np[validCubes])
+    param_sub['xyz'] = xyz_new
+    out.update(prediction_list=p_l, rgb_list=rgb_l, vxl_ijk_list=ijk_l, rayPooling_votes_list=v_l, param_np=param_sub[nonempty],
+               viewPair_np=viewPairs4Reconstr.astype(np.uint16)[nonempty], cube_ijk_np=cubes_param_np['ijk'][validCubes][nonempty])
     # :172-173 thinning
     out["vxl_mask_list"] = sparseCubes.filter_voxels(vxl_mask_list=[], prediction_list=out["prediction_list"], prob_thresh=tau,
                                                      rayPooling_votes_list=out["rayPooling_votes_list"], rayPool_thresh=gamma * N_vp * 2)

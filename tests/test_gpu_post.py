@@ -187,6 +187,10 @@ def test_sparse_loop_device_chain_equals_piecewise(sn, n_vp, crop):
         got = loop.run(sc["pairs"], sc["xyz"], sc["resol"], sc["w"])
         got2 = loop.run(sc["pairs"][:2], sc["xyz"][:2], sc["resol"][:2], sc["w"][:2])      # buffers are reusable, shorter batch
         loop.close()
+        small = reconstruct.SparseLoop(ctx, n_vp, max_cubes=2, min_prob=thr, rayPool_thresh=0, enable_centerCrop=crop,
+                                       cube_Dcenter=12 if crop else None, enable_rayPooling=True)
+        many = small.run_many(sc["pairs"], sc["xyz"], sc["resol"], sc["w"])            # 5 cubes through 2-cube batches, pipelined
+        small.close()
     p16, rgb8 = post_oracle.to_sparse_inputs(fused, rgb)
     want = post_oracle.dense2sparse(p16, rgb8, sc["xyz"], sc["resol"], sc["pairs"], min_prob=thr, rayPool_thresh=0, enable_centerCrop=crop,
                                     cube_Dcenter=12 if crop else None, enable_rayPooling=True, cameraPOs=sc["cams"])
@@ -196,6 +200,10 @@ def test_sparse_loop_device_chain_equals_piecewise(sn, n_vp, crop):
     assert all(np.array_equal(a.view(np.uint16), b.view(np.uint16)) for a, b in zip(got[2], want[2]))
     assert np.array_equal(got[5], want[5])
     assert got2[0] == [i for i in want[0] if i < 2]
+    assert many[0] == want[0] and np.array_equal(many[5], want[5])
+    for k in (1, 3, 4):
+        assert all(np.array_equal(a, b) for a, b in zip(many[k], want[k])), k
+    assert all(np.array_equal(a.view(np.uint16), b.view(np.uint16)) for a, b in zip(many[2], want[2]))
     assert all(np.array_equal(a, b) for a, b in zip(got2[1], want[1]))
 
 
