@@ -166,7 +166,8 @@ static TileChoice tile_for(const LayerSpec &sp, int split)
     if (sp.cout == 32) return {2, 1, 1};
     if (sp.cout == 80) return {5, 1, split == 2 ? 1 : 2};
     if (sp.cout == 160) return {5, 2, split == 2 ? 1 : 2};
-    return {7, 1, 1};  // cout 100
+    // cout 100 (merge_conv_a/b). f16 mode has LDS room for two 8-channel groups per slab in merge_conv_a (-18 % there)
+    return {7, 1, (split == 0 && sp.cin == 64) ? 2 : 1};
 }
 
 template <int SPLIT>
@@ -210,8 +211,9 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
 #define CONV2 3, 1, 4, 5, EPI_STORE, SP, (SP == 2 ? 1 : 2), (SP == 2 ? 2 : 1), 8, 0
 #define CONV3 3, 1, 4, 5, EPI_STORE, SP, (SP == 2 ? 1 : 2), (SP == 2 ? 2 : 1), 8, 0
 #define CONV4 3, 2, 4, 5, EPI_STORE, SP, 1, 2, 8, 0
-#define MERGA 3, 1, 4, 7, EPI_STORE, SP, 1, 2, 8, 0
-#define MERGB 3, 1, 4, 7, EPI_FINAL, SP, 1, 2, 8, 0
+// f16 mode (one activation plane): 4-chunk weight pieces halve the barriers; merge_conv_a also takes 16-channel slabs
+#define MERGA 3, 1, 4, 7, EPI_STORE, SP, (SP == 0 ? 2 : 1), (SP == 0 ? 4 : 2), 8, 0
+#define MERGB 3, 1, 4, 7, EPI_FINAL, SP, 1, (SP == 0 ? 4 : 2), 8, 0
     auto &L = c->conv;
     RUN((launch_conv<CONV1>(c, L["conv1_1"], x0, 8, a1, 32, 0, 32, nullptr, S, s)));
     RUN((launch_conv<CONV1>(c, L["conv1_2"], a1, 32, b1, 32, 0, 32, nullptr, S, s)));
@@ -232,15 +234,17 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     RUN((launch_conv<CONV4>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<SIDE>(c, L["side_op4"], a4, 304, s4, 16, 0, 16, nullptr, S, D3)));
     RUN((launch_up3<SP>(c, s2, s3, s4, cat, S, s, 64)));
-    if (SP == 1 && c->tail_m8) {
-        // f16x3 default: merge_conv_a writes its output in the f16m8 storage format and merge_conv_b computes in f16m8
-        // (main term f16, both correction terms on one MX-fp8 MFMA): -14 % on the dominant kernel for +1e-5 of L_inf
-        RUN((launch_conv<3, 1, 4, 7, EPI_STORE, SP, 1, 2, 8, 0, 0, 2>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
-        RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
-    } else {
-        RUN((launch_conv<MERGA>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
-        RUN((launch_conv<MERGB>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
+    if constexpr (SP == 1) {
+        if (c->tail_m8) {
+            // f16x3 default: merge_conv_a writes its output in the f16m8 storage format and merge_conv_b computes in f16m8
+            // (main term f16, both correction terms on one MX-fp8 MFMA): -14 % on the dominant kernel for +1e-5 of L_inf
+            RUN((launch_conv<3, 1, 4, 7, EPI_STORE, 1, 1, 2, 8, 0, 0, 2>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
+            RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
+            return SN_OK;
+        }
     }
+    RUN((launch_conv<MERGA>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
+    RUN((launch_conv<MERGB>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
 #undef RUN
     return SN_OK;
 }
