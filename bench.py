@@ -85,6 +85,36 @@ def fast_mode(surfacenet_amd, scene, values, s, n, n_vp, device, steps):
             "note": "operands rounded to fp16: L_inf vs fp64 oracle 1e-3..4e-3 on BN-calibrated nets (above the 1e-3 bar) - not the headline"}
 
 
+def s64_mode(surfacenet_amd, values, n_vp, device, steps, precision, n=8):
+    """Extra, non-headline measurement: the same hot path at s=64 (params.py:65 __cube_D = 64), n cubes x n_vp pairs per step
+    (8 x 2 x 64^3 voxels = the voxel count of the headline workload)."""
+    import golden_util
+    s = 64
+    scene = golden_util.synthetic_scene(n, n_vp, s=s, seed=0)
+    ctx = surfacenet_amd.Context(cube_D=s, max_samples=n * n_vp, device=device, precision=precision)
+    ctx.load_param_values(values)
+    ctx.set_cameras(scene["cams"]); ctx.set_images(scene["imgs"])
+    d = [ctx.upload(scene[k]) for k in ("pairs", "xyz", "resol", "w")]
+    d_fused = ctx.dev_alloc(n * s ** 3 * 4)
+    for _ in range(2):
+        ctx.cvc_forward_dev(n, n_vp, d[0], d[1], d[2], d[3], d_fused)
+    ctx.synchronize()
+    ctx.profile_reset(); ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.cvc_forward_dev(n, n_vp, d[0], d[1], d[2], d[3], d_fused)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    prof = ctx.profile()
+    ctx.close()
+    dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
+    ach = prof[dom]["flops"] / (prof[dom]["ms"] * 1e-3) / 1e12
+    return {"value": round(n * steps / el, 2), "unit": "cubes/s (s=64)", "ms_per_step": round(el / steps * 1e3, 3), "cubes_per_step": n, "n_vp": n_vp,
+            "equivalent_s32_cubes_per_s": round(8 * n * steps / el, 1),
+            "roofline": {"bound": "mfma", "kernel": "conv3d_f16_mfma<%s>" % dom, "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4)}}
+
+
 def post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, steps, keep_frac=0.1):
     """Extra, non-headline measurement: the whole loop body of main_reconstruct.py:134-160 --
     hot path + voxel colours + ray pooling + dense2sparse -- device-resident (reconstruct.SparseLoop), packed sparse
@@ -181,6 +211,7 @@ def main():
                     help="f16x3 (default): hi/lo split fp16 operands, fp32-class results (parity grade); f16: fast mode, L_inf ~2e-3")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16 fast-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-s64", action="store_true", help="skip the extra s=64 measurement")
     ap.add_argument("--no-simil", action="store_true", help="skip the extra similarityNet (early rejection) measurement")
     ap.add_argument("--no-post-pass", action="store_true", help="skip the extra whole-loop-body (ray pooling / dense2sparse) measurement")
     args = ap.parse_args()
@@ -313,6 +344,8 @@ def main():
                                    "FLOP (2 in the last 3x3x3 layer, whose correction terms run on the MX-fp8 MFMA), so its ceiling is frac = 1/3 .. 1/2" if args.precision.startswith("f16x3") else "achieved = algorithmic conv FLOPs / kernel time")
         if world == 1 and args.precision == "f16x3" and not args.no_fast_mode:
             out["fast_mode_f16"] = fast_mode(surfacenet_amd, scene, values, s, n, n_vp, local_rank, max(3, args.steps // 2))
+        if world == 1 and s == 32 and not args.no_s64:
+            out["s64"] = s64_mode(surfacenet_amd, values, n_vp, local_rank, max(3, args.steps // 2), args.precision)
         if world == 1 and not args.no_post_pass:
             out["loop_body_with_post_pass"] = post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, max(3, args.steps // 2))
         if world == 1 and not args.no_simil:
