@@ -89,6 +89,7 @@ extern "C" int sn_dense2sparse_dev(sn_ctx *c, int n, int n_vp, const int64_t *pa
 {
     if (!c || !cfg || !pred_dev || !offsets_dev || !ijk_dev || !pred16_dev) return fail(SN_ERR_ARG, "null argument");
     if (n < 1 || n_vp < 1) return fail(SN_ERR_ARG, "bad n / n_vp");
+    if (rgb_out_dev && !rgb_dev) return fail(SN_ERR_ARG, "rgb_out requested without rgb");
     HIPCHK(hipSetDevice(c->device));
     int lo, dc, rc;
     if ((rc = sparse_geometry(c, cfg, lo, dc)) != SN_OK) return rc;
