@@ -586,22 +586,42 @@ conv3d_f16_mfma(ConvArgs a)
                 }
             }
         } else if constexpr (EPI == EPI_STORE) {
+            // Lane (v, kq) holds channels 4kq..4kq+3 of 16-channel fragment n: the 16-byte group of a voxel is split between lanes
+            // l (kq even) and l+16 (kq odd). Two voxel fragments (m, m+1) are finished together and their halves exchanged with
+            // v_permlane16_swap (lanes 16-31 / 48-63 of the first operand <-> lanes 0-15 / 32-47 of the second; tools/probe/
+            // swap_probe.hip): afterwards the even-kq lanes hold the whole group of fragment m, the odd-kq lanes that of m+1,
+            // and every lane issues ONE 16-byte store per plane instead of two 8-byte ones (the tail is store-issue bound).
+            static_assert(MF % 2 == 0, "paired store epilogue");
+            const bool odd = kq & 1;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int m = 0; m < MF; ++m) {
-                const int gx = x0 + (C::F4 ? wave * MF + m : wave * C::XS + (m >> 2)), gy = y0 + (C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3)), gz = z0 + (C::F4 ? (v & 3) : (v & 7));
-                const bool valid = gx < DX && gy < D && gz < D;
-                const size_t vlin = ((size_t)gx * D + gy) * D + gz;
+            for (int mp = 0; mp < MF; mp += 2) {
+                bool valid[2];
+                size_t vlin[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int m = mp + e;
+                    const int gx = x0 + (C::F4 ? wave * MF + m : wave * C::XS + (m >> 2)), gy = y0 + (C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3)), gz = z0 + (C::F4 ? (v & 3) : (v & 7));
+                    valid[e] = gx < DX && gy < D && gz < D;
+                    vlin[e] = ((size_t)gx * D + gy) * D + gz;
+                }
+                const bool my_valid = odd ? valid[1] : valid[0];
+                const size_t my_vlin = odd ? vlin[1] : vlin[0];
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
-                    if (valid && nl < a.out_cp) {
-                        const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.scale + nl);
-                        const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + NF * 16 + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                    const bool ch_ok = nl < a.out_cp;                    // out_cp is a multiple of 8: both lanes of a pair agree
+                    const int nlc = ch_ok ? nl : 0;
+                    const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.scale + nlc);
+                    const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + NF * 16 + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.shift + nlc);
+                    unsigned hw[2][2], lw[2][2];                          // [fragment of the pair][dword]: hi plane, second plane
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
                         half4 h, l;
                         float lo32[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float y = acc[m][n][r] * sc[r] + sh[r];
+                            float y = acc[mp + e][n][r] * sc[r] + sh[r];
                             y = a.act == 0 ? fmaxf(y, 0.f) : sn_sigmoid(y);
                             if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
@@ -612,16 +632,32 @@ conv3d_f16_mfma(ConvArgs a)
                                 lo32[r] = (y - (float)h[r]) * 4096.f;
                             }
                         }
-                        const int ch = a.out_coff + nl;   // group-blocked layout: [b][ch/8][x][y][z][ch%8]
-                        _Float16 *o = a.out + (size_t)b * VOL * a.out_cs + ((size_t)(ch >> 3) * VOL + vlin) * 8 + (ch & 7);
-                        *reinterpret_cast<half4 *>(o) = h;
-                        if constexpr (OSPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
-                        if constexpr (OSPLIT == 2) {
+                        const uint2 hb = __builtin_bit_cast(uint2, h);
+                        hw[e][0] = hb.x; hw[e][1] = hb.y;
+                        if constexpr (OSPLIT == 1) {
+                            const uint2 lb = __builtin_bit_cast(uint2, l);
+                            lw[e][0] = lb.x; lw[e][1] = lb.y;
+                        } else if constexpr (OSPLIT == 2) {
                             // second plane, 16-byte slot per (voxel, group): [fp8(hi) c0..c7 | fp8(lo*2^12) c0..c7]
-                            char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.out_lo_off);
-                            *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                            *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                            lw[e][0] = (unsigned)sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                            lw[e][1] = (unsigned)sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
                         }
+                    }
+                    // r[0] = {own (even kq) | lower partner's fragment-(m+1) half (odd kq)}, r[1] = {upper partner's fragment-m half | own}
+                    const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
+                    const auto h1 = __builtin_amdgcn_permlane16_swap(hw[0][1], hw[1][1], false, false);
+                    const int ch = a.out_coff + (nl & ~7);               // first channel of this lane pair's 8-channel group
+                    _Float16 *o = a.out + (size_t)b * VOL * a.out_cs + ((size_t)(ch >> 3) * VOL + my_vlin) * 8;
+                    const bool st = my_valid && ch_ok;
+                    if (st) *reinterpret_cast<u32x4 *>(o) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+                    if constexpr (OSPLIT == 1) {
+                        const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
+                        const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
+                        if (st) *reinterpret_cast<u32x4 *>(o + a.out_lo_off) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+                    } else if constexpr (OSPLIT == 2) {
+                        const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);   // fp8(hi) words
+                        const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);   // fp8(lo) words
+                        if (st) *reinterpret_cast<u32x4 *>(o + a.out_lo_off) = u32x4{l0[0], l0[1], l1[0], l1[1]};
                     }
                 }
             }
