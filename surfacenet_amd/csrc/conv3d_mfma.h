@@ -212,7 +212,9 @@ conv3d_f16_mfma(ConvArgs a)
     // issued before it (measured: 21 us per tile of serialised store->load round trips in merge_conv_a)
     float *const cst = reinterpret_cast<float *>(lds + 2 * C::XBUF + 2 * C::WBUF + 2 * C::KOFF_N * 4);   // [2][NF*16]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to hipcc: without the readfirstlane every
+    // loop and LDS-DMA destination indexed by it becomes an EXEC-masked (waterfall) loop (guide T20)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v = lane & 15, kq = lane >> 4;
     const int D = a.D, DX = a.DX;
     const size_t VOL = (size_t)DX * D * D;
