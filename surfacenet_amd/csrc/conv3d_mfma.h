@@ -272,19 +272,14 @@ conv3d_f16_mfma(ConvArgs a)
     };
     // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n; raw s_barrier (a __syncthreads() would make hipcc drain
     // vmcnt(0) because LDS-DMAs are pending, defeating the counted wait)
+    // s_waitcnt vmcnt(n) takes an immediate: the run-time (wave-uniform) n is quantised DOWN to {0, 2, 3, 4} (waiting for more than
+    // asked is always safe; the common instalment sizes are exact) so that the choice costs two or three scalar branches, not a
+    // nine-way switch
     auto wait_vmcnt = [&](int n) {
-        switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
+        if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     auto wg_barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
     auto write_koff = [&](int c8n, int kb) {
