@@ -249,6 +249,8 @@ conv3d_f16_mfma(ConvArgs a)
     // segments are dealt round-robin to the waves; this call issues this wave's instructions [k0, k0+kn) and
     // returns how many it really issued (the tail waves own one segment less).
     constexpr int HT = (C::NSEG * NPL + C::NW - 1) / C::NW;   // halo DMA instructions per wave and slab
+    constexpr int FULLP = ((C::NTAP * C::CS8MAX + 3) / 4 + C::PCH - 1) / C::PCH;      // weight pieces of a full channel slab
+    constexpr int HQ = FULLP > 1 ? (HT + FULLP - 2) / (FULLP - 1) : HT;                 // halo DMA instalment per piece
     auto stage_halo = [&](int t, int c0, int c8n, int xb, int k0, int kn) -> int {
         int b, x0, y0, z0;
         tile_origin(t, b, x0, y0, z0);
@@ -272,15 +274,6 @@ conv3d_f16_mfma(ConvArgs a)
     };
     // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n; raw s_barrier (a __syncthreads() would make hipcc drain
     // vmcnt(0) because LDS-DMAs are pending, defeating the counted wait)
-    // s_waitcnt vmcnt(n) takes an immediate: the run-time (wave-uniform) n is quantised DOWN to {0, 2, 3, 4} (waiting for more than
-    // asked is always safe; the common instalment sizes are exact) so that the choice costs two or three scalar branches, not a
-    // nine-way switch
-    auto wait_vmcnt = [&](int n) {
-        if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
     auto wg_barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
     auto write_koff = [&](int c8n, int kb) {
         const int G = C::NTAP * c8n, nchunk = (G + 3) >> 2;
@@ -365,7 +358,8 @@ conv3d_f16_mfma(ConvArgs a)
             if (have_next) write_koff(nc8n, xb ^ 1);
             // the next halo tile is fetched in npiece-1 instalments, each issued right after a weight piece so that a
             // counted vmcnt can wait for the weights while the newest halo DMAs stay in flight
-            const int hq = npiece > 1 ? (HT + npiece - 2) / (npiece - 1) : HT;
+            // Instalment size HQ is a compile-time constant (sized for a full slab) so that the wait in front of the barrier is a
+            // fixed s_waitcnt vmcnt(HQ) or vmcnt(0), one scalar branch; the last instalment of a short slab takes whatever is left.
             int hdone = 0;
 
             // ---- software-pipelined K loop over this slab ----------------------------------------------------
@@ -422,8 +416,10 @@ conv3d_f16_mfma(ConvArgs a)
                 }
                 int hnow = 0;
                 if (have_next && !(SN_ABL & 1) && hdone < HT && (p + 1 < npiece || npiece == 1)) {
-                    hnow = stage_halo(ntile, nc0, nc8n, xb ^ 1, hdone, hq < HT - hdone ? hq : HT - hdone);
-                    hdone += hq;
+                    const int left = HT - hdone;
+                    const int kn = (p + 2 >= npiece || left < HQ) ? left : HQ;
+                    hnow = stage_halo(ntile, nc0, nc8n, xb ^ 1, hdone, kn);
+                    hdone += kn;
                 }
                 static_for<0, C::PCH>([&](auto ccc) {
                     constexpr int cc = decltype(ccc)::value;
@@ -518,7 +514,9 @@ conv3d_f16_mfma(ConvArgs a)
                 });
                 lgkm_wait<0>();
                 if constexpr (!(SN_ABL & 2)) {
-                    wait_vmcnt(p + 1 == npiece ? 0 : hnow);   // next weight piece landed; the newest halo DMAs may still fly
+                    // next weight piece landed; the newest HQ halo DMAs (issued after it) may still fly
+                    if (p + 1 != npiece && hnow >= HQ) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HQ) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     wg_barrier();                             // ... for every wave; this piece's buffers are free again
                 }
                 wbi ^= 1;
