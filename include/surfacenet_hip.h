@@ -196,6 +196,14 @@ int sn_embeddingpair2simil(sn_ctx *ctx, int n_pairs, const float *emb_pairs, flo
  * through sn_embeddingpair2simil, without shipping every embedding once per pair across PCIe. */
 int sn_embeddings2simil(sn_ctx *ctx, int n_cubes, int n_views, const float *embeddings, float *similarity);
 
+/* camera.perspectiveProj (utils/camera.py:123-184; calls at main_reconstruct.py:62-65 through perspectiveProj_cubesCorner):
+ * V cameras x n points in one launch. P (V,3,4) float64 row-major, or NULL = the cameras of sn_set_cameras (V ignored);
+ * xyz (n,3) float64 -> img_h, img_w (V,n) float64 (row v = camera v), depth (V,n) or NULL. Same arithmetic as the CVC
+ * warp's projection (fp64 FMA chain over k, IEEE divide); round_int != 0 applies numpy's .round() (half-to-even) - the
+ * caller casts to int64. */
+int sn_project_points(sn_ctx *ctx, int V, const double *P, int n, const double *xyz, int round_int, double *img_h,
+                      double *img_w, double *depth);
+
 /* ---- multi-GPU (one process per GPU): the path's only exchange is an all-gather of the per-cube fused probabilities
  * (the reference is single-GPU, no counterpart). RCCL over xGMI; librccl is dlopen'ed on first use.
  * Rank 0 calls sn_comm_unique_id and ships the 128 bytes to the other ranks by any means; every rank then calls

@@ -14,9 +14,10 @@ from . import runtime, weights
 
 def SurfaceNet_inference(N_viewPairs4inference, model_file, layerNameList_2_load=None, cube_D=None, param_values=None):
     """model_file: the reference's `*.model` pickle. `param_values` (list of arrays in weight-file order) may be given
-    instead, e.g. weights.synthetic_param_values(seed). cube_D defaults to runtime.DEFAULT_CUBE_D (params.py:65)."""
+    instead, e.g. weights.synthetic_param_values(seed). cube_D = None (default): inferred from X.shape at every call of
+    nViewPair_SurfaceNet_fn (the reference fixes it at compile time from params.__cube_D, params.py:65: 64, or 32), so the
+    drop-in accepts whichever of the two the caller's params selects; an int pins it (any other X then raises TypeError)."""
     values = param_values if param_values is not None else weights.load_lasagne_pickle(model_file)
-    cube_D = runtime.DEFAULT_CUBE_D if cube_D is None else cube_D
     runtime.set_param_values(values)
     N_vp = int(N_viewPairs4inference)
 
@@ -24,7 +25,7 @@ def SurfaceNet_inference(N_viewPairs4inference, model_file, layerNameList_2_load
         f = np.asarray(similFeature)
         if f.dtype != np.float32 or f.ndim != 2:
             raise TypeError("similFeature must be a float32 matrix")
-        ctx = runtime.context_for(cube_D, n_samples=1)
+        ctx = runtime.any_context() if cube_D is None else runtime.context_for(cube_D, n_samples=1)
         return ctx.relative_weights(f, int(n_samples_perGroup))
 
     def nViewPair_SurfaceNet_fn(X, *args, **kwargs):
@@ -44,7 +45,9 @@ def SurfaceNet_inference(N_viewPairs4inference, model_file, layerNameList_2_load
                 n_per = int(args[1])
         if not isinstance(X, np.ndarray) or X.dtype != np.float32 or X.ndim != 5:
             raise TypeError("X must be a float32 5-D ndarray")
-        ctx = runtime.context_for(cube_D, n_samples=X.shape[0])
+        if X.shape[1] != 6 or X.shape[2] != X.shape[3] or X.shape[3] != X.shape[4]:
+            raise TypeError("X must have shape (N*n_vp, 6, s, s, s), got %s" % (X.shape,))
+        ctx = runtime.context_for(X.shape[2] if cube_D is None else cube_D, n_samples=X.shape[0])
         fused, unfused = ctx.forward(X, w, n_vp=n_per, return_unfused=True)
         if N_vp == 1:
             return [fused, fused]      # both outputs are the same tensor in the reference (SurfaceNet.py:355-357)

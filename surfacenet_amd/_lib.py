@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "sn_cvc_forward_dev", "sn_cvc_dev", "sn_forward_dev",
     "sn_ray_pool", "sn_ray_pool_dev", "sn_dense2sparse", "sn_dense2sparse_dev",
     "sn_simil_load_weights", "sn_crop_patches", "sn_patch2embedding", "sn_crop_embed", "sn_embeddingpair2simil", "sn_embeddings2simil",
+    "sn_project_points",
     "sn_comm_unique_id", "sn_comm_init", "sn_allgather_f32_dev",
     "sn_profile_enable", "sn_profile_count", "sn_profile_get", "sn_profile_reset",
 ]
@@ -92,6 +93,7 @@ def load():
         "sn_crop_embed": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
         "sn_embeddingpair2simil": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
         "sn_embeddings2simil": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+        "sn_project_points": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
         "sn_comm_unique_id": (c_int, [ctypes.c_char_p]),
         "sn_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p]),
         "sn_allgather_f32_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

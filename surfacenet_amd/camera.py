@@ -1,56 +1,47 @@
-"""Host-side projection helpers of the reference's `utils/camera.py` that feed early rejection:
-O(N_views * N_cubes * 8) float64 arithmetic, kept in numpy with the reference's exact operation order.
+"""Drop-in for the projection entry points of the reference's `utils/camera.py` that the reconstruction pipeline calls
+(main_reconstruct.py:62-65), executed on the MI355X through `sn_project_points`:
 
-    cameraPs2Ts                  utils/camera.py:87-120   (camera centres by cofactors, as the reference computes them)
-    perspectiveProj              utils/camera.py:123-184
-    perspectiveProj_cubesCorner  utils/camera.py:188-245
-(`viewPairAngles_wrt_pts` lives in surfacenet_amd/viewPairSelection.py.)
+    perspectiveProj              utils/camera.py:123-184   -> Context.project (project_points_kernel, csrc/postpass.h)
+    perspectiveProj_cubesCorner  utils/camera.py:188-245   -> the 8 corners of every cube through the same kernel
+
+Same signatures, result shapes / dtypes and ValueError contract as the reference; the arithmetic (fp64 FMA chain, IEEE
+divide, half-to-even rounding) is the CVC warp's and is checked bit for bit against vectors produced by the reference
+(`tests/test_gpu_dropin.py`). No CPU implementation lives here. The camera file readers and `cameraPs2Ts` stay with the
+caller (host I/O, out of scope); the camera centres the view-pair angles need are computed in
+`viewPairSelection.camera_centers`.
 """
 import numpy as np
 
+from . import runtime
+
+_CORNER_OFFSETS = np.array([[i, j, k] for i in (0, 1) for j in (0, 1) for k in (0, 1)])   # corner c = 4i + 2j + k, as np.indices((2,2,2))
+
+
+def _project(projection_M, pts, return_int_hw, return_depth):
+    M = np.asarray(projection_M)
+    if M.shape[-2:] != (3, 4) or M.ndim not in (2, 3):
+        raise ValueError("perspectiveProj needs projection_M with shape (3,4), however got {}".format(M.shape))
+    res = runtime.any_context().project(pts, projection_M=M.reshape((-1, 3, 4)), return_int_hw=return_int_hw, return_depth=return_depth)
+    return res if M.ndim == 3 else tuple(r[0] for r in res)       # one matrix: (N_pts,) results, a stack: (N_Ms, N_pts)
+
 
 def perspectiveProj(projection_M, xyz_3D, return_int_hw=True, return_depth=False):
-    """projection_M (3,4)/(N_Ms,3,4), xyz_3D (3,)/(N_pts,3) -> img_h, img_w [, depth]: (N_pts,) / (N_Ms, N_pts)."""
-    projection_M = np.asarray(projection_M)
-    xyz_3D = np.asarray(xyz_3D)
-    if projection_M.shape[-2:] != (3, 4):
-        raise ValueError("perspectiveProj needs projection_M with shape (3,4), however got {}".format(projection_M.shape))
-    if xyz_3D.ndim == 1:
-        xyz_3D = xyz_3D[None, :]
-    if xyz_3D.ndim != 2 or xyz_3D.shape[1] != 3:
-        raise ValueError("perspectiveProj needs xyz_3D with shape (3,) or (N_pts, 3), however got {}".format(xyz_3D.shape))
-    xyz1 = np.c_[xyz_3D, np.ones((xyz_3D.shape[0], 1))].astype(np.float64)
-    pts_3D = np.matmul(projection_M, xyz1.T)
-    pts_2D = pts_3D[..., :2, :]
-    pts_2D /= pts_3D[..., 2:3, :]
-    if return_int_hw:
-        pts_2D = pts_2D.round().astype(np.int64)
-    img_w, img_h = pts_2D[..., 0, :], pts_2D[..., 1, :]
-    if return_depth:
-        return img_h, img_w, pts_3D[..., 2, :]
-    return img_h, img_w
+    """img_h, img_w [, depth] of the points xyz_3D (3,) / (N_pts,3) under projection_M (3,4) / (N_Ms,3,4)."""
+    pts = np.asarray(xyz_3D)
+    if pts.ndim == 1:
+        pts = pts[None, :]
+    if pts.ndim != 2 or pts.shape[1] != 3:
+        raise ValueError("perspectiveProj needs xyz_3D with shape (3,) or (N_pts, 3), however got {}".format(pts.shape))
+    return _project(projection_M, pts, return_int_hw, return_depth)
 
 
 def perspectiveProj_cubesCorner(projection_M, cube_xyz_min, cube_D_mm, return_int_hw=True, return_depth=False):
-    """Projections of the 8 corners of every cube: img_h, img_w of shape (N_Ms, N_cubes, 8)."""
-    cube_xyz_min = np.asarray(cube_xyz_min)
-    if cube_xyz_min.ndim == 1:
-        cube_xyz_min = cube_xyz_min[None, :]
-    if cube_xyz_min.ndim != 2 or cube_xyz_min.shape[1] != 3:
-        raise ValueError("perspectiveProj needs cube_xyz_min with shape (3,) or (N_pts, 3), however got {}".format(cube_xyz_min.shape))
-    N_pts = cube_xyz_min.shape[0]
-    shift = np.indices((2, 2, 2)).reshape((3, -1)).T[None, :, :] * cube_D_mm
-    corners = cube_xyz_min[:, None, :] + shift
-    img_h, img_w = perspectiveProj(projection_M, corners.reshape((N_pts * 8, 3)), return_int_hw=return_int_hw, return_depth=False)
-    return img_h.reshape((-1, N_pts, 8)), img_w.reshape((-1, N_pts, 8))
-
-
-def cameraPs2Ts(cameraPOs):
-    """Camera centres (N,3) (or a list, if a list is given) of projection matrices (3,4): the null vector of P by
-    cofactor expansion, C_i = (-1)^i det(P without column i), de-homogenised (utils/camera.py:87-120)."""
-    def center(P):
-        P = np.asarray(P)
-        cof = np.array([(-1) ** i * np.linalg.det(P[:, [j for j in range(4) if j != i]]) for i in range(4)])
-        return cof[:3] / cof[3]
-    Ts = [center(P) for P in cameraPOs]
-    return Ts if type(cameraPOs) is list else np.stack(Ts)
+    """img_h, img_w of the 8 corners of every cube, shape (N_Ms, N_cubes, 8) (N_Ms = 1 for a single matrix)."""
+    lo = np.asarray(cube_xyz_min)
+    if lo.ndim == 1:
+        lo = lo[None, :]
+    if lo.ndim != 2 or lo.shape[1] != 3:
+        raise ValueError("perspectiveProj needs cube_xyz_min with shape (3,) or (N_pts, 3), however got {}".format(lo.shape))
+    corners = lo[:, None, :] + _CORNER_OFFSETS[None] * cube_D_mm          # numpy promotion as in the reference (int64 * scalar + array)
+    h, w = _project(projection_M, corners.reshape((-1, 3)), return_int_hw, False)
+    return h.reshape((-1, lo.shape[0], 8)), w.reshape((-1, lo.shape[0], 8))

@@ -215,6 +215,26 @@ class Context(object):
         _lib.check(self._lib.sn_embeddings2simil(self._h, e.shape[0], e.shape[1], _lib.ptr(e), _lib.ptr(out)))
         return out
 
+    def project(self, xyz_3D, projection_M=None, return_int_hw=True, return_depth=False):
+        """camera.perspectiveProj (utils/camera.py:123-184) of (n,3) points through V cameras in one launch: projection_M
+        (V,3,4) float64, or None = the cameras of set_cameras -> img_h, img_w [, depth], each (V, n); int64 when
+        return_int_hw (numpy's .round().astype(int64)), else float64."""
+        pts = np.ascontiguousarray(xyz_3D, dtype=np.float64)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points must have shape (n, 3), got %s" % (pts.shape,))
+        M = None if projection_M is None else np.ascontiguousarray(projection_M, dtype=np.float64)
+        if M is not None and (M.ndim != 3 or M.shape[1:] != (3, 4)):
+            raise ValueError("projection_M must have shape (V, 3, 4), got %s" % (M.shape,))
+        n, V = pts.shape[0], (self.n_cameras if M is None else M.shape[0])
+        h = np.empty((V, n), dtype=np.float64)
+        w = np.empty((V, n), dtype=np.float64)
+        d = np.empty((V, n), dtype=np.float64) if return_depth else None
+        _lib.check(self._lib.sn_project_points(self._h, V, _lib.ptr(M), n, _lib.ptr(pts), 1 if return_int_hw else 0, _lib.ptr(h), _lib.ptr(w),
+                                               _lib.ptr(d)))
+        if return_int_hw:
+            h, w = h.astype(np.int64), w.astype(np.int64)
+        return (h, w, d) if return_depth else (h, w)
+
     # ---- post-pass (SURVEY §8f row N2) ----------------------------------------------------------------
     def ray_pool(self, selected_viewPairs, xyz, resol, prediction, prediction_thresh=None):
         """rayPooling.rayPooling_1cube_numpy (utils/rayPooling.py:143-260) for n cubes: prediction (n,s,s,s) (or

@@ -118,7 +118,7 @@ __device__ __forceinline__ void up_axis(int o, int n_in, int &m, float &wa, floa
 // contiguous bytes (per plane) that follow side_op1's 16 channels in the ConcatLayer buffer (nets/SurfaceNet.py:71).
 // One thread = one output voxel of one of the 6 destination 8-channel groups (consecutive threads = consecutive z:
 // fully coalesced 16-byte stores in the group-blocked layout [b][group][x][y][z][8]).
-template <int SPLIT>
+template <int SPLIT, int OSPLIT = SPLIT>
 __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, const _Float16 *s3, const _Float16 *s4, _Float16 *cat,
                                                             int Do, int cat_cs, long long total, long long lo2, long long lo3,
                                                             long long lo4, long long out_lo_off)
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, 
         }
     }
     _Float16 *o = cat + ((((b * (cat_cs >> 3) + 2 + g) * Do + x) * Do + y) * Do + z) * 8LL;
-    sn_store8<SPLIT>(o, out_lo_off, acc);
+    sn_store8<OSPLIT>(o, out_lo_off, acc);   // OSPLIT: storage format the consumer (merge_conv_a) computes in
 }
 
 // unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.

@@ -154,12 +154,15 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
             const double Z = __dadd_rn(__dmul_rn((double)kz, r), z0);
             const double q0 = sn_dot4(P, X, Y, Z), q1 = sn_dot4(P + 4, X, Y, Z), q2 = sn_dot4(P + 8, X, Y, Z);
             const double w = rint(__ddiv_rn(q0, q2)), h = rint(__ddiv_rn(q1, q2)), d = rint(__ddiv_rn(q2, r));
-            const double lim = 2147483647.0;
-            if (!(w >= -lim && w <= lim && h >= -lim && h <= lim && d >= -lim && d <= lim)) {
+            // pixel key = (w, h) with the sign bits flipped: (-1,-1), a legal out-of-image pixel (the reference's ray pooling has no
+            // in-image test), would otherwise equal the RP_EMPTY sentinel; the one pair that still does, (2^31-1, 2^31-1), is
+            // rejected through the err path together with everything outside the int32 range
+            const double lim = 2147483647.0, limp = 2147483646.0;
+            if (!(w >= -lim && w <= limp && h >= -lim && h <= limp && d >= -lim && d <= lim)) {
                 *a.err = 1;
             } else {
                 const int wi = (int)w, hi = (int)h, di = (int)d;
-                const unsigned ps = rp_insert(pix_key, mask, ((unsigned long long)(unsigned)wi << 32) | (unsigned)hi);
+                const unsigned ps = rp_insert(pix_key, mask, ((unsigned long long)((unsigned)wi ^ 0x80000000u) << 32) | ((unsigned)hi ^ 0x80000000u));
                 q = rp_insert(cell_key, mask, ((unsigned long long)ps << 32) | (unsigned)di);
                 atomicMax(cell_idx + q, (unsigned)i);
                 dmin_t = min(dmin_t, di);
@@ -210,6 +213,27 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
     }
     __syncthreads();
     if (tid == 0 && sh_i[2]) rp_vote(votes, 0u, mult);
+}
+
+// ------------------------------------------------------------------------------------------------
+// point projection (camera.perspectiveProj, utils/camera.py:123-184): every bound camera x every point.
+// One thread = one (view, point): q = P.[x y z 1] as the FMA chain over k (what numpy's matmul -> dgemm computes), IEEE
+// divides by q2, optional rint (numpy .round(): half-to-even). Outputs are float64 (V, n) row-major; lanes run along the
+// points, so the three loads per lane are strided by 24 B and the stores are contiguous.
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) project_points_kernel(const double *cams, const double *xyz, int n, int round_int,
+                                                                    double *out_h, double *out_w, double *out_depth)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double *P = cams + (size_t)blockIdx.y * 12;
+    const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+    const double q0 = sn_dot4(P, X, Y, Z), q1 = sn_dot4(P + 4, X, Y, Z), q2 = sn_dot4(P + 8, X, Y, Z);
+    double w = __ddiv_rn(q0, q2), h = __ddiv_rn(q1, q2);
+    if (round_int) { w = rint(w); h = rint(h); }
+    const size_t o = (size_t)blockIdx.y * n + i;
+    out_h[o] = h; out_w[o] = w;
+    if (out_depth) out_depth[o] = q2;
 }
 
 // ------------------------------------------------------------------------------------------------

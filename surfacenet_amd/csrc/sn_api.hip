@@ -181,12 +181,12 @@ static int launch_pool(sn_ctx *c, const char *tag, Act in, Act out, int B, int D
     return SN_OK;
 }
 
-template <int SPLIT>
+template <int SPLIT, int OSPLIT = SPLIT>
 static int launch_up3(sn_ctx *c, Act s2, Act s3, Act s4, Act cat, int B, int Do, int cat_cs)
 {
     const long long total = (long long)B * Do * Do * Do * 6;
     ProfScope ps(c, "side_op234_deconv", 0, (double)B * Do * Do * Do * 48 * 2.0 * (SPLIT ? 2 : 1));
-    hipLaunchKernelGGL((upsample3_cat_kernel<SPLIT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, s2.p, s3.p, s4.p,
+    hipLaunchKernelGGL((upsample3_cat_kernel<SPLIT, OSPLIT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, s2.p, s3.p, s4.p,
                        cat.p, Do, cat_cs, total, s2.lo, s3.lo, s4.lo, cat.lo);
     HIPCHK(hipGetLastError());
     return SN_OK;
@@ -218,7 +218,11 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     RUN((launch_conv<CONV1>(c, L["conv1_1"], x0, 8, a1, 32, 0, 32, nullptr, S, s)));
     RUN((launch_conv<CONV1>(c, L["conv1_2"], a1, 32, b1, 32, 0, 32, nullptr, S, s)));
     RUN((launch_conv<CONV1>(c, L["conv1_3"], b1, 32, a1, 32, 0, 32, nullptr, S, s)));
-    RUN((launch_conv<SIDE>(c, L["side_op1"], a1, 32, cat, 64, 0, 16, nullptr, S, s)));
+    // f16x3 default (tail_m8 == 2): merge_conv_a AND merge_conv_b compute in f16m8 (main term f16, both correction terms on one MX-fp8
+    // MFMA), so everything that writes the concat buffer stores it in the f16m8 format (OSPLIT = 2); upstream stays three-fp16-MFMA.
+    const bool cat_m8 = SP == 1 && c->tail_m8 >= 2;
+    if (cat_m8) { if constexpr (SP == 1) RUN((launch_conv<1, 1, 4, 1, EPI_STORE, 1, 5, 2, 4, 0, 0, 2>(c, L["side_op1"], a1, 32, cat, 64, 0, 16, nullptr, S, s))); }
+    else RUN((launch_conv<SIDE>(c, L["side_op1"], a1, 32, cat, 64, 0, 16, nullptr, S, s)));
     RUN((launch_pool<SP>(c, "pool1", a1, p1, S, s, 32)));
     RUN((launch_conv<CONV2>(c, L["conv2_1"], p1, 32, a2, 80, 0, 80, nullptr, S, D2)));
     RUN((launch_conv<CONV2>(c, L["conv2_2"], a2, 80, b2, 80, 0, 80, nullptr, S, D2)));
@@ -233,11 +237,16 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     RUN((launch_conv<CONV4>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<CONV4>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<SIDE>(c, L["side_op4"], a4, 304, s4, 16, 0, 16, nullptr, S, D3)));
-    RUN((launch_up3<SP>(c, s2, s3, s4, cat, S, s, 64)));
+    if (cat_m8) { if constexpr (SP == 1) RUN((launch_up3<1, 2>(c, s2, s3, s4, cat, S, s, 64))); }
+    else RUN((launch_up3<SP>(c, s2, s3, s4, cat, S, s, 64)));
     if constexpr (SP == 1) {
-        if (c->tail_m8) {
-            // f16x3 default: merge_conv_a writes its output in the f16m8 storage format and merge_conv_b computes in f16m8
-            // (main term f16, both correction terms on one MX-fp8 MFMA): -14 % on the dominant kernel for +1e-5 of L_inf
+        if (c->tail_m8 >= 2) {
+            RUN((launch_conv<3, 1, 4, 7, EPI_STORE, 2, 1, 2, 8, 0>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
+            RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
+            return SN_OK;
+        }
+        if (c->tail_m8 == 1) {
+            // merge_conv_a (three-fp16-MFMA) writes its output in the f16m8 storage format and merge_conv_b computes in f16m8
             RUN((launch_conv<3, 1, 4, 7, EPI_STORE, 1, 1, 2, 8, 0, 0, 2>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
             RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
             return SN_OK;
@@ -376,7 +385,8 @@ int sn_set_precision(sn_ctx *c, int mode)
     if (c->have_weights && mode != c->mode) c->have_weights = false;   // weights must be re-packed for the new mode
     c->mode = mode;
     c->split = mode == SN_PRECISION_F16X3_PURE ? 1 : mode;
-    c->tail_m8 = mode == SN_PRECISION_F16X3;
+    c->tail_m8 = mode == SN_PRECISION_F16X3 ? 2 : 0;
+    if (mode == SN_PRECISION_F16X3 && getenv("SN_M8_TAIL")) c->tail_m8 = std::max(0, std::min(2, atoi(getenv("SN_M8_TAIL"))));   // A/B measurements only
     return SN_OK;
 }
 
@@ -467,7 +477,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
         }
         PackedConv L;
         L.name = sp.name; L.cin = sp.cin; L.cout = sp.cout; L.ks = k; L.dil = (sp.kind == K_DIL3) ? 2 : 1; L.act = sp.act;
-        const int lsplit = (c->split == 1 && c->tail_m8 && L.name == "merge_conv_b") ? 2 : c->split;   // see run_net_t
+        const int lsplit = (c->split == 1 && ((c->tail_m8 >= 1 && L.name == "merge_conv_b") || (c->tail_m8 >= 2 && L.name == "merge_conv_a"))) ? 2 : c->split;   // see run_net_t
         const TileChoice tc = tile_for(sp, lsplit);
         if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit)) != SN_OK) return rc;
         c->conv[L.name] = L;
@@ -708,19 +718,16 @@ int sn_relative_weights(sn_ctx *c, int n, int n_vp, const float *features, float
     if (!c->have_relw) return fail(SN_ERR_STATE, "the relative-weight MLP arrays (params 98..104) were not loaded");
     HIPCHK(hipSetDevice(c->device));
     const size_t rows = (size_t)n * n_vp;
-    float *d_f = nullptr, *d_z = nullptr, *d_o = nullptr;
-    HIPCHK(hipMalloc((void **)&d_f, rows * kDFeature * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&d_z, rows * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&d_o, rows * sizeof(float)));
+    TmpDev t;      // freed on every return path
+    float *d_f = t.get<float>(rows * kDFeature), *d_z = t.get<float>(rows), *d_o = t.get<float>(rows);
+    if (!d_f || !d_z || !d_o) return fail(SN_ERR_NOMEM, "sn_relative_weights: device allocation failed");
     HIPCHK(hipMemcpyAsync(d_f, features, rows * kDFeature * sizeof(float), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(relw_mlp_kernel, dim3((unsigned)rows), dim3(128), 0, c->stream, d_f, c->relw_W1, c->relw_scale, c->relw_shift,
                        c->relw_w2, c->relw_b2, d_z, kDFeature, kHidden);
     hipLaunchKernelGGL(relw_softmax_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c->stream, d_z, d_o, n, n_vp);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(weights, d_o, rows * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_f); (void)hipFree(d_z); (void)hipFree(d_o);
-    if (e != hipSuccess) return fail(SN_ERR_HIP, "relative-weight MLP failed: %s", hipGetErrorString(e));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(weights, d_o, rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return SN_OK;
 }
 

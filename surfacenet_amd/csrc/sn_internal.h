@@ -75,7 +75,8 @@ struct sn_ctx {
     bool have_weights = false, have_relw = false;
     int split = 1;              // 0: f16 operands; 1: f16x3 (hi/lo split operands, fp32-class results) — default; 2: f16m8
     int mode = 1;               // the SN_PRECISION_* value given to sn_set_precision
-    bool tail_m8 = true;        // f16x3: merge_conv_b (the last 3x3x3 layer) runs its two correction terms on the MX-fp8 MFMA
+    int tail_m8 = 2;            // f16x3: how many of the last 3x3x3 layers run their two correction terms on the MX-fp8 MFMA
+                                // (0 none = f16x3p, 1 merge_conv_b, 2 merge_conv_a + merge_conv_b); env SN_M8_TAIL overrides (A/B runs)
     bool ws_ready = false; int ws_split = -1;
     std::map<std::string, PackedConv> conv;
     float *w3 = nullptr; float scale3 = 0, shift3 = 0;

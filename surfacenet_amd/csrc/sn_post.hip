@@ -198,3 +198,35 @@ extern "C" int sn_dense2sparse(sn_ctx *c, int n, int n_vp, const int64_t *pairs,
     }
     return SN_OK;
 }
+
+// camera.perspectiveProj (utils/camera.py:123-184): V cameras x n points in one launch (see project_points_kernel).
+extern "C" int sn_project_points(sn_ctx *c, int V, const double *P, int n, const double *xyz, int round_int, double *img_h, double *img_w,
+                                 double *depth)
+{
+    if (!c || !xyz || !img_h || !img_w) return fail(SN_ERR_ARG, "null argument");
+    if (n < 0) return fail(SN_ERR_ARG, "n must be >= 0");
+    if (!P) {
+        if (!c->cams) return fail(SN_ERR_STATE, "P == NULL selects the cameras of sn_set_cameras, which has not been called");
+        V = c->V_cam;
+    } else if (V < 1) return fail(SN_ERR_ARG, "V must be >= 1");
+    if (n == 0) return SN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t tot = (size_t)V * n;
+    TmpDev t;
+    double *d_x = t.get<double>((size_t)n * 3), *d_h = t.get<double>(tot), *d_w = t.get<double>(tot), *d_d = depth ? t.get<double>(tot) : nullptr;
+    double *d_P = P ? t.get<double>((size_t)V * 12) : c->cams;
+    if (!d_x || !d_h || !d_w || !d_P || (depth && !d_d)) return fail(SN_ERR_NOMEM, "sn_project_points: device allocation failed");
+    if (P) HIPCHK(hipMemcpyAsync(d_P, P, sizeof(double) * 12 * V, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_x, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, "project_points", 0, (double)n * 24.0 + (double)tot * (depth ? 24.0 : 16.0));
+        hipLaunchKernelGGL(project_points_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)V), dim3(256), 0, c->stream, d_P, d_x, n, round_int,
+                           d_h, d_w, d_d);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(img_h, d_h, sizeof(double) * tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(img_w, d_w, sizeof(double) * tot, hipMemcpyDeviceToHost, c->stream));
+    if (depth) HIPCHK(hipMemcpyAsync(depth, d_d, sizeof(double) * tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}

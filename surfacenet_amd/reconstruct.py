@@ -294,7 +294,7 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
     img_h_cubesCenter, img_w_cubesCenter = camera.perspectiveProj(projection_M=cameraPOs_np, xyz_3D=cubes_param_np['xyz'] + cube_D_mm / 2.,
                                                                   return_int_hw=False, return_depth=False)
     N_views, N_cubes = img_h_cubesCorner.shape[:2]
-    cameraTs_np = camera.cameraPs2Ts(cameraPOs=cameraPOs_np)                                    # main_reconstruct.py:50
+    cameraTs_np = viewPairSelection.camera_centers(cameraPOs_np)                                    # main_reconstruct.py:50
     # :84-97 early rejection
     viewPairs = viewPairSelection.k_combination_np(range(N_views), k=2)
     patches_embedding, inScope_cubes_vs_views = earlyRejection.patch2embedding(

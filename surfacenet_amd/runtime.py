@@ -4,7 +4,7 @@ import numpy as np
 
 from .context import Context, MEAN_CVC_RGBRGB  # noqa: F401
 
-DEFAULT_CUBE_D = 32        # params.py:65 (__cube_D in {32, 64})
+DEFAULT_CUBE_D = 64        # params.py:65 (__cube_D = 64; {32, 64} are the supported sizes). The drop-in callables infer cube_D from X.shape.
 DEFAULT_MAX_SAMPLES = 64
 _device = 0
 _contexts = {}
@@ -13,7 +13,7 @@ _simil_values = None
 _scene_key = {}
 _cam_key = {}
 _img_key = {}
-_single_img_keepalive = {}
+_img_refs = {}      # id(ctx) -> (list object, [arrays]): strong references, so that the ids in a key can never be recycled
 
 
 def set_device(device):
@@ -41,16 +41,41 @@ def any_context():
     """A context for work that does not depend on cube_D (similarityNet, patch cropping)."""
     for ctx in _contexts.values():
         return ctx
-    return context_for(DEFAULT_CUBE_D)
+    return context_for(32)        # cube-size independent work: the smaller workspace
+
+
+def _fingerprint(im):
+    """Cheap content fingerprint of one image: shape, dtype and a checksum of a strided sample of its bytes (<= ~4k samples), so
+    that an image mutated in place, or a new array that landed on a freed array's address, is re-uploaded."""
+    a = np.asarray(im)
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 4096)
+    sample = np.ascontiguousarray(flat[::step])
+    return (a.shape, a.dtype.str, int(sample.view(np.uint8).astype(np.uint64).dot(np.arange(1, sample.nbytes + 1, dtype=np.uint64) % np.uint64(65521))))
+
+
+def _images_key(models_img):
+    return (id(models_img), len(models_img), tuple(id(im) for im in models_img), tuple(_fingerprint(im) for im in models_img))
+
+
+def invalidate(ctx=None):
+    """Forget what is bound (all contexts, or one): the next bind_* call uploads again. For callers that mutate images in
+    place beyond what the strided fingerprint can see."""
+    for d in (_scene_key, _cam_key, _img_key, _img_refs):
+        if ctx is None:
+            d.clear()
+        else:
+            d.pop(id(ctx), None)
 
 
 def bind_images(ctx, models_img):
     """Images only (patch cropping needs no cameras). Changing them drops the cached scene binding."""
-    key = (id(models_img), len(models_img), tuple(id(im) for im in models_img))
+    key = _images_key(models_img)
     if _img_key.get(id(ctx)) == key:
         return
     ctx.set_images(models_img)
     _img_key[id(ctx)] = key
+    _img_refs[id(ctx)] = (models_img, list(models_img))
     _scene_key.pop(id(ctx), None)
 
 
@@ -59,10 +84,10 @@ def bind_single_image(ctx, img):
     when it is not one of the bound images."""
     key = _img_key.get(id(ctx))
     if key is not None and id(img) in key[2]:
-        return key[2].index(id(img))
-    holder = [img]
-    _single_img_keepalive[id(ctx)] = holder
-    bind_images(ctx, holder)
+        v = key[2].index(id(img))
+        if key[3][v] == _fingerprint(img):
+            return v
+    bind_images(ctx, [img])
     return 0
 
 
@@ -83,7 +108,8 @@ def context_for(cube_D, n_samples=1):
 def bind_scene(ctx, cameraPOs, models_img):
     """Uploads cameras/images when they differ from what the context already holds (identity + cheap checks)."""
     cams = np.ascontiguousarray(cameraPOs, dtype=np.float64)
-    key = (id(models_img), len(models_img), tuple(id(im) for im in models_img), cams.tobytes())
+    ikey = _images_key(models_img)
+    key = ikey + (cams.tobytes(),)
     if _scene_key.get(id(ctx)) == key:
         return
     if len(models_img) != cams.shape[0]:
@@ -92,7 +118,8 @@ def bind_scene(ctx, cameraPOs, models_img):
     ctx.set_images(models_img)
     _scene_key[id(ctx)] = key
     _cam_key[id(ctx)] = cams.tobytes()
-    _img_key[id(ctx)] = key[:3]
+    _img_key[id(ctx)] = ikey
+    _img_refs[id(ctx)] = (models_img, list(models_img))
 
 
 def bind_cameras(ctx, cameraPOs):
@@ -113,3 +140,4 @@ def reset():
     _scene_key.clear()
     _cam_key.clear()
     _img_key.clear()
+    _img_refs.clear()

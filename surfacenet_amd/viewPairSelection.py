@@ -8,6 +8,7 @@ reference's small numpy bookkeeping — O(N_cubes * N_viewPairs) index work that
     k_combination_np        utils/utils.py:233-257
     yield_batch_npBool      utils/utils.py:149-177 (+ gen_batch_index :113-131)
     viewPairAngles_wrt_pts  utils/camera.py:275-309
+    camera_centers          (what utils/camera.py:87-120 cameraPs2Ts provides to the caller)
     __argmaxN_viewPairs__   utils/viewPairSelection.py:8-41   (ascending order kept: the largest weight is LAST)
     viewPairSelection       utils/viewPairSelection.py:44-82
 """
@@ -29,6 +30,14 @@ def yield_batch_npBool(N_all, batch_size):
         sel = np.zeros((N_all,), dtype=bool)
         sel[start:min(N_all, start + batch_size)] = True
         yield sel
+
+
+def camera_centers(cameraPOs):
+    """Camera centres (V,3) of projection matrices (V,3,4): the right null vector of P = [M | p4], i.e. C = -M^-1 p4, one batched
+    3x3 solve. (What the reference's camera.cameraPs2Ts, utils/camera.py:87-120, obtains from four 3x3 determinants; equal up to
+    rounding. Only the view-pair angles below consume it.)"""
+    P = np.asarray(cameraPOs, dtype=np.float64).reshape((-1, 3, 4))
+    return np.linalg.solve(P[:, :, :3], -P[:, :, 3:])[..., 0]
 
 
 def viewPairAngles_wrt_pts(cameraTs, pts_xyz):
@@ -76,7 +85,7 @@ def viewPairSelection(cameraTs_np, e_viewPairs, d_viewPairs, validCubes, cubeCen
             and np.array_equal(viewPairs, k_combination_np(range(N_views), k=2)):
         # all 2-combinations in combinations order: the GPU assembles the feature rows itself (bit-identical to the loop below)
         from . import runtime
-        ctx = runtime.context_for(viewPair_relativeImpt_fn.sn_cube_D)
+        ctx = runtime.any_context() if viewPair_relativeImpt_fn.sn_cube_D is None else runtime.context_for(viewPair_relativeImpt_fn.sn_cube_D)
         w_viewPairs = ctx.viewpair_weights(e_valid, d[..., 0].astype(np.float32), theta[..., 0].astype(np.float32))
         return __argmaxN_viewPairs__(viewPairs=viewPairs, w_viewPairs=w_viewPairs, N_argmax=N_viewPairs4inference)
     for _batch in yield_batch_npBool(N_all=N_validCubes, batch_size=int(math.floor(float(batchSize) / N_viewPairs))):

@@ -51,11 +51,12 @@ def test_cvc_bad_view_index(sn):
 
 
 # Tolerances (surface probabilities, L_inf):
-#   f16x3 (default, parity grade) vs the fp64 oracle: north-star bar 1e-3; observed ~1e-5, asserted < 1e-4
+#   f16x3 (default, parity grade: every layer up to the concat on three fp16 MFMAs, the two merge layers - 65 % of the MACs - with
+#   their correction terms on the MX-fp8 MFMA) vs the fp64 oracle: north-star bar 1e-3; observed 3e-5 .. 7e-5, asserted < 2e-4
 #   f16 (fast mode): vs fp64 < 1e-2 (observed 1e-3..4e-3: does NOT meet the 1e-3 bar, hence opt-in); vs the oracle that
 #   emulates fp16 operand storage < 5e-3 (same noise class as the storage rounding itself, because a different
 #   summation order flips half-ulp fp16 roundings of stored activations)
-TOL_X3, TOL_F16_EMU, TOL_F16 = 1e-4, 5e-3, 1e-2
+TOL_X3, TOL_F16_EMU, TOL_F16 = 2e-4, 5e-3, 1e-2
 TOL_X3P = 5e-5
 #   f16m8 (f16 main term + MX-fp8 correction terms): vs fp64 < 5e-4 (observed ~1e-4; north-star bar 1e-3); vs the oracle
 #   that emulates its storage/operand formats < 2e-4
@@ -83,7 +84,7 @@ def test_forward_vs_oracle(sn, s, n, n_vp, precision):
     assert u64.std() > 0.05 and u64.min() < 0.2 and u64.max() > 0.8          # the test net is not degenerate
     e_ref, e_fused = np.abs(unfused - u64).max(), np.abs(fused - f64).max()
     print("%s s=%d: L_inf vs fp64 oracle: unfused %.3e fused %.3e" % (precision, s, e_ref, e_fused))
-    if precision == "f16x3":         # default: f16x3 with merge_conv_b's correction terms on the MX-fp8 MFMA (observed ~2e-5)
+    if precision == "f16x3":         # default: f16x3 with the merge layers' correction terms on the MX-fp8 MFMA (observed 3e-5 .. 7e-5)
         assert e_ref < TOL_X3 and e_fused < TOL_X3
     elif precision == "f16x3p":      # every layer on three fp16 MFMAs (observed ~1e-5)
         assert e_ref < TOL_X3P and e_fused < TOL_X3P

@@ -41,7 +41,7 @@ def test_reconstruct_scene_equals_reference_style_script(gpu_required):
                                         batchSize_nViewPair_SurfaceNet=4, min_prob=min_prob, tau=tau, gamma=gamma)
 
     # ---- the reference's script, line by line, on the drop-in modules (host arrays everywhere) ----
-    cameraTs = camera.cameraPs2Ts(P)
+    cameraTs = viewPairSelection.camera_centers(P)
     ih, iw = camera.perspectiveProj_cubesCorner(P, cubes["xyz"], cube_D_mm, return_int_hw=False)
     ch, cw = camera.perspectiveProj(P, cubes["xyz"] + cube_D_mm / 2., return_int_hw=False)
     viewPairs = viewPairSelection.k_combination_np(range(4), k=2)

@@ -1,4 +1,4 @@
-"""Pins the early-rejection host logic (surfacenet_amd/{earlyRejection,image,camera}.py) and oracle/simil_oracle.py's
+"""Pins the early-rejection host logic (surfacenet_amd/{earlyRejection,image}.py) and oracle/simil_oracle.py's
 patch cropping against outputs of the reference's own functions (tests/golden/simil_cases.npz; generator:
 oracle/gen_golden_simil.py), and cross-checks the two formulations of the similarityNet oracle."""
 import os
@@ -8,8 +8,9 @@ import pytest
 
 import golden_util
 from oracle import simil_oracle
-from surfacenet_amd import camera, earlyRejection, image, weights
-from surfacenet_amd.viewPairSelection import k_combination_np
+from oracle import cvc_oracle
+from surfacenet_amd import earlyRejection, image, weights
+from surfacenet_amd.viewPairSelection import camera_centers, k_combination_np
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "simil_cases.npz"))
 
@@ -27,16 +28,24 @@ def test_preprocess_patches_matches_reference():
     assert np.array_equal(simil_oracle.preprocess(G["pre_in"], G["pre_mean"]), G["pre_out"])
 
 
+def _oracle_corners(P, xyz_min, cube_D_mm, return_int_hw):
+    """perspectiveProj_cubesCorner (utils/camera.py:188-245) on the oracle's projection: (N_Ms, N_cubes, 8)."""
+    xyz_min = np.atleast_2d(np.asarray(xyz_min))
+    corners = xyz_min[:, None, :] + np.indices((2, 2, 2)).reshape((3, -1)).T[None] * cube_D_mm
+    h, w = cvc_oracle.perspectiveProj(P, corners.reshape((-1, 3)), return_int_hw=return_int_hw)
+    return h.reshape((-1, xyz_min.shape[0], 8)), w.reshape((-1, xyz_min.shape[0], 8))
+
+
 def test_cube_corner_projection_and_scope_check_match_reference():
-    h, w = camera.perspectiveProj_cubesCorner(G["cc_doc_Ms"], G["cc_doc_pts"], cube_D_mm=1, return_int_hw=False)   # camera.py:211-216 doctest
+    """The oracle's projection against the reference-run corner / centre vectors (the product's GPU projection is checked
+    against the same vectors in tests/test_gpu_dropin.py); the in-scope test is host logic of the product."""
+    h, w = _oracle_corners(G["cc_doc_Ms"], G["cc_doc_pts"], 1, False)                           # camera.py:211-216 doctest
     assert np.array_equal(h, G["cc_doc_h"]) and np.array_equal(w, G["cc_doc_w"])
     assert np.allclose(w[:, :, 0], [[1.35860185, 0.9878389], [0.64522543, 0.76079278]])
-    hi, wi = camera.perspectiveProj_cubesCorner(G["cc_doc_Ms"][1], G["cc_doc_pts"][0], cube_D_mm=1, return_int_hw=True)
-    assert hi.shape == (1, 1, 8) and hi.dtype == np.int64
     D = np.float32(G["sc_D"])
-    h, w = camera.perspectiveProj_cubesCorner(G["sc_P"], G["sc_xyz"], cube_D_mm=D, return_int_hw=False)
+    h, w = _oracle_corners(G["sc_P"], G["sc_xyz"], D, False)
     assert np.array_equal(h, G["sc_img_h"]) and np.array_equal(w, G["sc_img_w"])
-    ch, cw = camera.perspectiveProj(G["sc_P"], G["sc_xyz"] + D / 2., return_int_hw=False)
+    ch, cw = cvc_oracle.perspectiveProj(G["sc_P"], G["sc_xyz"] + D / 2., return_int_hw=False)
     assert np.array_equal(ch, G["sc_ctr_h"]) and np.array_equal(cw, G["sc_ctr_w"])
     hw = tuple(int(v) for v in G["sc_hw"])
     ins = np.stack([image.img_hw_cubesCorner_inScopeCheck(hw, h[v], w[v]) for v in range(h.shape[0])])
@@ -92,6 +101,6 @@ def test_camera_centres_doctest():
     P = np.array([[798.693916, -2438.153488, 1568.674338, -542599.034996], [-44.838945, 1433.912029, 2576.399630, -1176685.647358],
                   [-0.840873, -0.344537, 0.417405, 382.793511]])                      # utils/camera.py:91-95 doctest
     t = np.array([555.64348632032, 191.10837560939, 360.02470478273])
-    assert np.allclose(camera.cameraPs2Ts(P[None])[0], t)
-    assert isinstance(camera.cameraPs2Ts([P]), list)
-    assert np.allclose(P @ np.r_[camera.cameraPs2Ts(P[None])[0], 1.0], 0, atol=1e-6)
+    assert np.allclose(camera_centers(P[None])[0], t)
+    assert camera_centers([P, P]).shape == (2, 3)
+    assert np.allclose(P @ np.r_[camera_centers(P)[0], 1.0], 0, atol=1e-6)

@@ -79,7 +79,7 @@ def main():
                                               N_views=a.views, batchSize=100000)
     valid = earlyRejection.selectFromSimilarity(dis, a.n_vp)
     lap("pair_similarity")
-    vp, w = viewPairSelection.viewPairSelection(camera.cameraPs2Ts(P), emb, dis, valid, cubes["xyz"] + cube_D_mm / 2., relw_fn, 100000, a.n_vp, viewPairs)
+    vp, w = viewPairSelection.viewPairSelection(viewPairSelection.camera_centers(P), emb, dis, valid, cubes["xyz"] + cube_D_mm / 2., relw_fn, 100000, a.n_vp, viewPairs)
     lap("viewpair_selection")
     t0 = time.perf_counter()
     res = reconstruct.reconstruct_scene(imgs, P, cubes, cube_D_mm, s, a.n_vp, p2e, pair_fn, relw_fn, cube_Dcenter=Dc, patches_mean_bgr=mean_bgr)
