@@ -160,6 +160,17 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_dst_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_dst_wave_base, 16, 0, AUX);
 }
 
+// The same through a buffer descriptor: lanes whose byte offset fails the descriptor's range check (offset >= num_records, which
+// includes "negative" offsets) deposit ZEROS in LDS (tools/probe/buflds_probe.hip) - the hardware does the 'same' padding.
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, void *lds_dst_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst_wave_base, 16, (int)voff, 0, 0, 0);
+}
+// Halo-voxel validity bits kept in the top bits of a lane's precomputed halo offset (see stage_halo_buf): a set bit that applies to
+// the tile at hand stays in the offset and pushes it out of the descriptor's range.
+constexpr unsigned HB_ALWAYS = 1u << 31, HB_XLO = 1u << 30, HB_XHI = 1u << 29, HB_YLO = 1u << 28, HB_YHI = 1u << 27, HB_ZLO = 1u << 26,
+                   HB_ZHI = 1u << 25, HB_OFFMASK = (1u << 25) - 1;
+
 template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_, int K2D = 0>
 struct ConvCfg {
     static constexpr int R = (KS / 2) * DIL;
@@ -250,7 +261,8 @@ conv3d_f16_mfma(ConvArgs a)
     // returns how many it really issued (the tail waves own one segment less).
     constexpr int HT = (C::NSEG * NPL + C::NW - 1) / C::NW;   // halo DMA instructions per wave and slab
     constexpr int FULLP = ((C::NTAP * C::CS8MAX + 3) / 4 + C::PCH - 1) / C::PCH;      // weight pieces of a full channel slab
-    constexpr int HQ = FULLP > 1 ? (HT + FULLP - 2) / (FULLP - 1) : HT;                 // halo DMA instalment per piece
+    // halo DMA instalment per piece (generic path); the buffer path issues its whole (cheap) set behind the first weight piece of a slab
+    constexpr int HQ = (K2D == 0) ? HT : (FULLP > 1 ? (HT + FULLP - 2) / (FULLP - 1) : HT);
     auto stage_halo = [&](int t, int c0, int c8n, int xb, int k0, int kn) -> int {
         int b, x0, y0, z0;
         tile_origin(t, b, x0, y0, z0);
@@ -270,6 +282,71 @@ conv3d_f16_mfma(ConvArgs a)
             dma16<SN_HALO_AUX>(ok ? (const void *)p : a.zero_page, xbuf + xb * C::XBUF + pl * C::XPLANE + seg * 1024);
             ++issued;
         }
+        return issued;
+    };
+    // ---- buffer-addressed halo staging (3-D nets) ------------------------------------------------------------------
+    // The generic stage_halo above spends ~35 VALU + ~30 SALU instructions and an EXEC-masked branch per 1 KiB DMA on turning
+    // (segment, lane) into a clamped global address. Here every lane keeps, per DMA slot k of its wave, ONE precomputed word:
+    // the byte offset of its halo voxel relative to the tile's halo origin inside the channel slab, plus validity bits for the six
+    // volume faces (and "never valid" for the tail of the last segment). Per DMA: (word & keep-mask of the tile) + tile offset ->
+    // voffset of a buffer_load..lds whose descriptor covers exactly the slab's c8n group planes of the sample; a voxel outside
+    // the volume keeps a high bit, fails the range check, and the hardware writes zeros ('same' padding / PadLayer).
+    // Precondition (checked by launch_conv): only the first / last tile along an axis has out-of-volume halo voxels, and
+    // CS8MAX * VOL * 16 + halo slack < 2^25 bytes.
+    constexpr bool BUFH = (K2D == 0);
+    unsigned hword[HT];
+    if constexpr (BUFH) {
+        const int xl = (a.tiles_x - 1) * C::TX, yl = (a.tiles_y - 1) * C::TY, zl = (a.tiles_z - 1) * C::TZ;
+        static_for<0, HT>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const int li = k * C::NW + wave;
+            const int seg = li % C::NSEG;
+            const int slot = seg * 64 + lane;
+            const int hv = slot / C::SLOTS, part = slot - hv * C::SLOTS;
+            const int hz = hv % C::HZ, hy = (hv / C::HZ) % C::HY, hx = hv / (C::HZ * C::HY);
+            unsigned o = ((unsigned)part * (unsigned)VOL + (unsigned)((hx * D + hy) * D + hz)) * 16u;
+            if (hv >= C::HVOX || li >= C::NSEG * NPL) o = HB_ALWAYS;
+            if (hx < C::RX) o |= HB_XLO;
+            if (xl - C::RX + hx >= DX) o |= HB_XHI;
+            if (hy < C::R) o |= HB_YLO;
+            if (yl - C::R + hy >= D) o |= HB_YHI;
+            if (hz < C::R) o |= HB_ZLO;
+            if (zl - C::R + hz >= D) o |= HB_ZHI;
+            hword[k] = o;
+        });
+    }
+    // tile-dependent scalars of the buffer path: keep-mask and byte offset of the halo origin (may be negative)
+    auto tile_halo_consts = [&](int x0, int y0, int z0, unsigned &keep, int &toff) {
+        unsigned inv = HB_ALWAYS;
+        if (x0 == 0) inv |= HB_XLO;
+        if (x0 == (a.tiles_x - 1) * C::TX) inv |= HB_XHI;
+        if (y0 == 0) inv |= HB_YLO;
+        if (y0 == (a.tiles_y - 1) * C::TY) inv |= HB_YHI;
+        if (z0 == 0) inv |= HB_ZLO;
+        if (z0 == (a.tiles_z - 1) * C::TZ) inv |= HB_ZHI;
+        keep = HB_OFFMASK | inv;
+        toff = (((x0 - C::RX) * D + (y0 - C::R)) * D + (z0 - C::R)) * 16;
+    };
+    // issues this wave's halo DMAs [k0, k0+kn) of (sample b, channel groups [c0, c0+c8n)) into halo buffer xb
+    // issues ALL of this wave's halo DMAs of (sample b, channel groups [c0, c0+c8n)) into halo buffer xb; returns how many
+    auto stage_halo_buf = [&](int b, unsigned keep, int toff, int c0, int c8n, int xb) -> int {
+        // opaque to the optimiser: otherwise it hoists (hword[k] & keep) + toff and the descriptors of BOTH candidate tiles out of the
+        // K loop as loop invariants (8 VGPRs + 16 SGPRs live across it) and the accumulators spill
+        asm volatile("" : "+s"(b), "+s"(keep), "+s"(toff), "+s"(c0));
+        const char *base0 = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)b * VOL * a.in_cs + (size_t)c0 * VOL * 8);
+        const int nrec = c8n * (int)VOL * 16;
+        int issued = 0;
+        static_for<0, HT>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const int li = k * C::NW + wave;
+            // (only the last slot of a wave can fall behind the last segment: HT = ceil(NSEG*NPL / NW))
+            if (k + 1 < HT || C::NSEG * NPL == HT * C::NW || li < C::NSEG * NPL) {
+                const char *base = (NPL > 1 && li >= C::NSEG) ? base0 + 2 * a.in_lo_off : base0;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, nrec, 0x00020000);
+                dma16_buf(rs, (hword[k] & keep) + (unsigned)toff, xbuf + xb * C::XBUF + li * 1024);
+                ++issued;
+            }
+        });
         return issued;
     };
     // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n; raw s_barrier (a __syncthreads() would make hipcc drain
@@ -315,7 +392,13 @@ conv3d_f16_mfma(ConvArgs a)
     // ---- prologue: first halo tile, its tap table, first weight piece ----------------------------------------
     {
         const int c8n = a.slab_c8[0];
-        stage_halo(tile, 0, c8n, 0, 0, HT);
+        if constexpr (BUFH) {
+            int b, x0, y0, z0, toff;
+            unsigned keep;
+            tile_origin(tile, b, x0, y0, z0);
+            tile_halo_consts(x0, y0, z0, keep, toff);
+            stage_halo_buf(b, keep, toff, 0, c8n, 0);
+        } else stage_halo(tile, 0, c8n, 0, 0, HT);
         write_koff(c8n, 0);
         const int nch = wchunks_of(c8n);
         stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
@@ -333,6 +416,17 @@ conv3d_f16_mfma(ConvArgs a)
     for (; tile < a.total_tiles; tile += tstride) {
         int b, x0, y0, z0;
         tile_origin(tile, b, x0, y0, z0);
+        // halo constants of this tile (later slabs) and of this workgroup's next tile (its first slab is staged during the last slab here)
+        int cur_toff = 0, nxt_toff = 0, nxt_b = 0;
+        unsigned cur_keep = 0, nxt_keep = 0;
+        if constexpr (BUFH) {
+            tile_halo_consts(x0, y0, z0, cur_keep, cur_toff);
+            if (tile + tstride < a.total_tiles) {
+                int nx0, ny0, nz0;
+                tile_origin(tile + tstride, nxt_b, nx0, ny0, nz0);
+                tile_halo_consts(nx0, ny0, nz0, nxt_keep, nxt_toff);
+            }
+        }
 
         f32x4 acc[MF][NF];
 #pragma unroll
@@ -415,7 +509,10 @@ conv3d_f16_mfma(ConvArgs a)
                     stage_w(nwoff, nch < C::PCH ? nch : C::PCH, wbi ^ 1);
                 }
                 int hnow = 0;
-                if (have_next && !(SN_ABL & 1) && hdone < HT && (p + 1 < npiece || npiece == 1)) {
+                if constexpr (BUFH) {
+                    if (have_next && !(SN_ABL & 1) && p == 0)
+                        hnow = stage_halo_buf(last_slab ? nxt_b : b, last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                } else if (have_next && !(SN_ABL & 1) && hdone < HT && (p + 1 < npiece || npiece == 1)) {
                     const int left = HT - hdone;
                     const int kn = (p + 2 >= npiece || left < HQ) ? left : HQ;
                     hnow = stage_halo(ntile, nc0, nc8n, xb ^ 1, hdone, kn);

@@ -31,17 +31,11 @@ def cameras():
 
 
 def synthetic_scene(n, n_vp=2, s=32, seed=0, hw=(1200, 1600)):
-    """SURVEY §8(d) synthetic workload: 2 random-noise views, DTU cameras 1,2, cube corners inside the view frusta."""
-    cams = cameras()["P_dtu"][:2]
-    imgs = [synth_image(1234 + v, hw[0], hw[1]) for v in range(2)]
-    rs = np.random.RandomState(seed)
-    span = 0.4 * s
-    xyz = (rs.rand(n, 3) * 40 + np.array([-20.0, -20.0, 580.0]) - np.array([0, 0, span / 2])).astype(np.float32)
-    resol = np.full(n, 0.4, dtype=np.float32)
-    pair_opts = np.array([[0, 1], [1, 0], [0, 0], [1, 1]], dtype=np.int64)
-    pairs = np.stack([pair_opts[(np.arange(n_vp) + i) % 4] for i in range(n)]).astype(np.int64)
-    w = (np.random.RandomState(seed + 1).rand(n, n_vp) + 0.1).astype(np.float32)
-    return dict(cams=cams, imgs=imgs, xyz=xyz, resol=resol, pairs=pairs, w=w)
+    """SURVEY §8(d) synthetic workload (surfacenet_amd/synthetic.py); the cameras are the reference-read DTU pair of the fixture."""
+    from surfacenet_amd import synthetic
+    sc = synthetic.synthetic_scene(n, n_vp, s=s, seed=seed, hw=hw)
+    assert np.array_equal(sc["cams"], cameras()["P_dtu"][:2])          # the literals in synthetic.py ARE pos_001/002.txt
+    return sc
 
 
 # Exactly-rounded stand-ins for the two network callables of utils/earlyRejection.py, used when the reference's host

@@ -62,3 +62,66 @@ def test_synthetic_scene_is_in_scope():
     sc = golden_util.synthetic_scene(4, 2, s=8, seed=0)
     out = cvc_oracle.gen_coloredCubes(sc["pairs"], sc["xyz"], sc["resol"], sc["cams"], sc["imgs"], 8)
     assert (out.reshape(8, 2, 3, -1).max(axis=2) > 0).mean() > 0.99    # all voxels in scope
+
+
+def test_cube_grid_matches_reference_initializeCubes():
+    """synthetic.cube_grid (the cube table the scene benches / tests feed the hot path) against tables produced by the reference's
+    own scene.initializeCubes (oracle/gen_golden_scene.py -> tests/golden/scene_cases.npz): DTU scan9 at s=32 (195,360 cubes =
+    BASELINE config 3) and s=64 (24,420, the count in the reference's log q.log/inference.0000022:116), Middlebury dino, doctest input."""
+    import os
+    from surfacenet_amd import synthetic
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "scene_cases.npz"))
+    cases = (("scan9_s32", (np.float32(0.4), 32, 26, 0.5, G["scan9_BB"])), ("scan9_s64", (np.float32(0.4), 64, 52, 0.5, G["scan9_BB"])),
+             ("dino_s32", (np.float32(0.00025), 32, 26, 0.5, G["dino_BB"])), ("doc", (1, 22, 10, 0.5, G["doc_BB"])))
+    for pre, args in cases:
+        cubes, dmm = synthetic.cube_grid(*args)
+        idx = G[pre + "_idx"]
+        assert cubes.dtype == synthetic.CUBE_DTYPE and cubes.shape[0] == int(G[pre + "_n"]) and float(dmm) == float(G[pre + "_cube_D_mm"])
+        assert np.array_equal(cubes["ijk"].max(axis=0) + 1, G[pre + "_grid"])
+        assert np.array_equal(cubes["xyz"][idx], G[pre + "_xyz"]) and np.array_equal(cubes["ijk"][idx], G[pre + "_ijk"])
+        assert np.array_equal(cubes["resol"][idx], G[pre + "_resol"])
+        w = np.arange(1, cubes.shape[0] + 1, dtype=np.float64)                       # checksums over ALL rows
+        assert np.array_equal(cubes["xyz"].astype(np.float64).sum(axis=0), G[pre + "_xyz_sum"])
+        assert np.array_equal((cubes["xyz"].astype(np.float64) * w[:, None]).sum(axis=0), G[pre + "_xyz_wsum"])
+    assert int(G["scan9_s32_n"]) == 195360 and int(G["scan9_s64_n"]) == 24420
+    assert G["P_dtu49"].shape == (49, 3, 4) and G["P_mid16"].shape == (16, 3, 4)
+    assert np.array_equal(G["P_dtu49"][:2], synthetic.P_DTU_12)
+
+
+def test_genuine_python2_pickle_weight_file(tmp_path):
+    """weights.load_lasagne_pickle on the byte format the reference's `.model` files really have (Python 2.7 cPickle protocol 2,
+    numpy 1.13: `numpy.core.multiarray._reconstruct`, py2 `str` payloads; nets/SurfaceNet.py:397-400) - tests/py2pickle.py emits
+    that stream opcode by opcode. A Python-3 `pickle.load` without encoding='latin1' cannot read it."""
+    import py2pickle
+    vals = weights.synthetic_param_values(7)
+    blob = py2pickle.dumps_py2(vals)
+    assert b"numpy.core.multiarray\n_reconstruct" in blob and blob[:2] == b"\x80\x02"
+    with pytest.raises(UnicodeDecodeError):
+        pickle.loads(blob)
+    p = tmp_path / "2D_2_3D-19-0.918_0.951.model"                          # params.py:106 file name
+    p.write_bytes(blob)
+    back = weights.load_lasagne_pickle(str(p))
+    assert len(back) == 105 and all(b.dtype == np.float32 and np.array_equal(a, b) for a, b in zip(vals, back))
+    sv = weights.synthetic_simil_param_values(2)
+    q = tmp_path / "epoch33_acc_tr0.707_val0.791.model"                     # params.py:91
+    q.write_bytes(py2pickle.dumps_py2(sv))
+    back = weights.load_simil_pickle(str(q))                                # same format (nets/similarityNet.py:240-242)
+    assert len(back) == 30 and all(np.array_equal(a, b) for a, b in zip(sv, back))
+
+
+def test_interpolation_kernel_pinned_to_reference_W_5D():
+    """The fixed stencil of Bilinear_3DInterpolation is the one CNN constant that can be pinned: oracle/gen_golden_w5d.py executed
+    the reference's own `__W_5D__` (nets/layers.py:361-372) -> tests/golden/w5d_cases.npz. The product's weight-file entry, the
+    oracle's restatement and (GPU test) the closed form inside upsample3_cat_kernel must all equal it."""
+    import os
+    from oracle import net_oracle
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "w5d_cases.npz"))
+    for f, k in ((2, 3), (4, 5)):
+        W = G["f%d_W" % f]
+        assert int(G["f%d_k" % f]) == k and W.shape == (1, 1, k, k, k) and W.dtype == np.float32
+        assert np.array_equal(weights.interpolation_kernel(k), W)
+        w1 = net_oracle.w5d(k)
+        assert np.array_equal((w1[:, None, None] * w1[None, :, None] * w1[None, None, :]).astype(np.float32), W[0, 0])
+    vals = weights.synthetic_param_values(0)
+    ups = [v for (layer, p, shape), v in zip(weights.PARAM_LAYOUT, vals) if layer.endswith("_deconv")]
+    assert [u.shape[2] for u in ups] == [3, 5, 5] and np.array_equal(ups[0], G["f2_W"]) and np.array_equal(ups[1], G["f4_W"])
