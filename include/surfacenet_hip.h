@@ -34,7 +34,8 @@ enum sn_status {
     SN_ERR_STATE = -2,   /* call order: weights / images / cameras not set                */
     SN_ERR_HIP = -3,     /* HIP runtime error; text carries hipGetErrorString             */
     SN_ERR_NOMEM = -4,
-    SN_ERR_COMM = -5
+    SN_ERR_COMM = -5,
+    SN_ERR_RANGE = -6    /* a conv layer stored a non-finite value or one beyond the fp16 range of its storage format */
 };
 
 /* One parameter array inside the weight blob (reference pickle = flat list of arrays,

@@ -79,7 +79,9 @@ struct ConvArgs {
     const float *scale;   // [nsplit*NF*16]
     const float *shift;
     const float *w3;      // EPI_FINAL: [NF*16] fp32 weights of the fused 1x1x1 conv
-    const void *zero_page;    // >= 16 zero bytes: source of out-of-volume / padding voxels
+    const void *zero_page;    // >= 16 zero bytes: source of out-of-volume / padding voxels (generic halo path of the 2-D nets)
+    unsigned *status;         // numeric status word of the context (or nullptr): status_bit is OR-ed in when an output value is not
+    unsigned status_bit;      // finite or exceeds the fp16 range its hi plane is stored in (|y| > 65504)
     float scale3, shift3;
     long long wsplit_stride;  // halfs between channel splits in wpack
     long long in_lo_off, out_lo_off;
@@ -412,6 +414,8 @@ conv3d_f16_mfma(ConvArgs a)
 #endif
     int xb = 0;     // halo / tap-table buffer holding the current slab
     int wbi = 0;    // weight buffer holding the current piece
+    bool bad = false;   // a stored value left the fp16 range / is NaN (checked on the fp32 value in the epilogue)
+    constexpr float kF16Max = 65504.f;
 
     for (; tile < a.total_tiles; tile += tstride) {
         int b, x0, y0, z0;
@@ -655,6 +659,7 @@ conv3d_f16_mfma(ConvArgs a)
                         float y = fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f);
                         y = fmaxf(y, __shfl_xor(y, 1));
                         y = fmaxf(y, __shfl_xor(y, YX));
+                        bad |= !(y <= kF16Max);
                         if constexpr (OSPLIT == 1) {
                             _Float16 hh, ll;
                             sn_split(y, hh, ll);
@@ -715,6 +720,7 @@ conv3d_f16_mfma(ConvArgs a)
                         for (int r = 0; r < 4; ++r) {
                             float y = acc[mp + e][n][r] * sc[r] + sh[r];
                             y = a.act == 0 ? fmaxf(y, 0.f) : sn_sigmoid(y);
+                            bad |= !(y <= kF16Max);          // (false for NaN: flagged too; y >= 0 after either activation)
                             if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
                                 sn_split(y, hh, ll);
@@ -773,10 +779,13 @@ conv3d_f16_mfma(ConvArgs a)
                 const size_t vox = ((size_t)(b * DX + gx) * D + gy) * D + gz;
                 p += __shfl_xor(p, 16);
                 p += __shfl_xor(p, 32);
-                if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(p * a.scale3 + a.shift3);
+                const float t = p * a.scale3 + a.shift3;
+                bad |= !(fabsf(t) <= 3.0e38f);                 // NaN / inf logit (an overflowed accumulator upstream)
+                if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(t);
             }
         }
     }
+    if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, a.status_bit);
 }
 
 }  // namespace sn

@@ -54,8 +54,16 @@ static unsigned char fp8_e4m3(float v)
 //   split 2 (f16m8): [slab][piece of 8 groups]{ chunk 2p: nf hi fragments | chunk 2p+1: nf hi fragments |
 //                     nf MX fragments (2 KiB: k bytes 0-15 of all 64 lanes, then 16-31); lane (row = l&15, q = l>>4): q<2 -> fp8(w_lo * 2^12) of
 //                     groups 8p+4q..+3, q>=2 -> fp8(w_hi) of groups 8p+4(q-2)..+3 }   (every piece is full-size, zero padded)
-int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const float *gamma, const float *mean,
-              const float *inv_std, int nf, int nsplit, int cs8max, int split)
+// Dynamic-range normalisation (exact: every factor is a power of two). The split-fp16 storage of weights and activations has
+// fp16's exponent range, so before packing
+//   * input channel c of the layer arrives pre-multiplied by 2^in_exp[c] (its producer's out_exp): W[o][c] *= 2^-in_exp[c];
+//   * every output row o is scaled by 2^r_o so that max_k |W[o][k]| lies in [1,2) (weights of any magnitude keep their full
+//     22 bits); the BN scale absorbs 2^-r_o;
+//   * a ReLU layer stores y * 2^out_exp[o] (ReLU commutes with positive scaling): scale and shift absorb 2^out_exp[o].
+// conv(2^a x) * 2^b == 2^(a+b) conv(x) exactly in binary floating point as long as nothing over/underflows, so the network
+// function is unchanged; in_exp / out_exp may be null (all zero).
+int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, const float *gamma, const float *mean,
+              const float *inv_std, int nf, int nsplit, int cs8max, int split, const int *in_exp, const int *out_exp)
 {
     L.nf = nf; L.nsplit = nsplit; L.cs8max = cs8max; L.split = split;
     L.cin_p = round_up(L.cin, 8);
@@ -65,6 +73,23 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const
     L.slab_c8.clear();
     for (int left = c8_total; left > 0; left -= cs8max) L.slab_c8.push_back((unsigned char)std::min(left, cs8max));
     if ((int)L.slab_c8.size() > kMaxSlab) return fail(SN_ERR_ARG, "%s: too many channel slabs", L.name.c_str());
+    std::vector<float> Wn((size_t)L.cout * L.cin * ntap);
+    std::vector<int> row_exp(L.cout, 0);
+    for (int o = 0; o < L.cout; ++o) {
+        float mx = 0.f;
+        for (int ci = 0; ci < L.cin; ++ci)
+            for (int t = 0; t < ntap; ++t) {
+                const size_t i = ((size_t)o * L.cin + ci) * ntap + t;
+                const float w = in_exp ? std::ldexp(W_in[i], -in_exp[ci]) : W_in[i];
+                if (!std::isfinite(w)) return fail(SN_ERR_ARG, "%s: non-finite weight (output channel %d, input channel %d)", L.name.c_str(), o, ci);
+                Wn[i] = w;
+                mx = std::max(mx, std::fabs(w));
+            }
+        if (mx > 0.f) row_exp[o] = -std::ilogb(mx);
+        if (row_exp[o] != 0)
+            for (size_t i = (size_t)o * L.cin * ntap; i < (size_t)(o + 1) * L.cin * ntap; ++i) Wn[i] = std::ldexp(Wn[i], row_exp[o]);
+    }
+    const float *W = Wn.data();
     auto wat = [&](int o, int c8abs, int j, int tap) -> float {
         const int ci = c8abs * 8 + j;
         return (o < L.cout && ci < L.cin) ? W[((size_t)o * L.cin + ci) * ntap + tap] : 0.f;
@@ -143,8 +168,12 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const
     std::vector<float> sc((size_t)nsplit * nf * 16 + 16, 0.f), sh((size_t)nsplit * nf * 16 + 16, 0.f);
     for (int o = 0; o < L.cout; ++o) {
         const float s = gamma[o] * inv_std[o];   // Lasagne BatchNormLayer, deterministic=True
-        sc[o] = s;
-        sh[o] = beta[o] - mean[o] * s;
+        const int oe = out_exp ? out_exp[o] : 0;
+        sc[o] = std::ldexp(s, oe - row_exp[o]);
+        sh[o] = std::ldexp(beta[o] - mean[o] * s, oe);
+        if (!std::isfinite(sc[o]) || !std::isfinite(sh[o]) || (s != 0.f && sc[o] == 0.f))
+            return fail(SN_ERR_ARG, "%s: folded BatchNorm scale / shift of output channel %d leaves the fp32 range (gamma %g, inv_std %g, "
+                                    "row exponent %d, output exponent %d)", L.name.c_str(), o, gamma[o], inv_std[o], row_exp[o], oe);
     }
     int rc;
     if ((rc = dev_alloc(c, &L.wpack, h.size() + 8192)) != SN_OK) return rc;
@@ -325,6 +354,7 @@ static int create_impl(sn_ctx *c)
     int rc;
 #define AL(p, n) do { if ((rc = dev_alloc(c, &c->p, (n))) != SN_OK) return rc; } while (0)
     AL(unf_ws, S * v1); AL(d_fused, S * v1);
+    AL(d_num, 1); HIPCHK(hipMemset(c->d_num, 0, sizeof(unsigned)));
     AL(d_pairs, S * 2); AL(d_xyz, S * 3); AL(d_resol, S); AL(d_w, S);
 #undef AL
     return SN_OK;
@@ -393,10 +423,22 @@ int sn_set_precision(sn_ctx *c, int mode)
 int sn_get_precision(sn_ctx *c) { return c ? c->mode : SN_ERR_ARG; }
 void *sn_stream(sn_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-int sn_synchronize(sn_ctx *c)
+// Waits for the context's stream and reports the asynchronous error words (numeric status of the conv layers, ray-pooling range).
+static int sync_check(sn_ctx *c)
 {
-    if (!c) return fail(SN_ERR_ARG, "null context");
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_num) {
+        unsigned st = 0;
+        HIPCHK(hipMemcpy(&st, c->d_num, sizeof st, hipMemcpyDeviceToHost));
+        if (st) {
+            HIPCHK(hipMemset(c->d_num, 0, sizeof st));
+            std::string names;
+            for (size_t i = 0; i < 32; ++i)
+                if (st & (1u << i)) names += (names.empty() ? "" : ", ") + (i < c->num_names.size() ? c->num_names[i] : std::string("similarityNet"));
+            return fail(SN_ERR_RANGE, "non-finite or fp16-overflowing activation (|y| > 65504) stored by layer(s): %s - the results of the calls since the last "
+                                      "sn_synchronize are invalid (weights outside the supported dynamic range, see DESIGN.md section 5)", names.c_str());
+        }
+    }
     if (c->d_err) {
         int e = 0;
         HIPCHK(hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
@@ -406,6 +448,12 @@ int sn_synchronize(sn_ctx *c)
         }
     }
     return SN_OK;
+}
+
+int sn_synchronize(sn_ctx *c)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    return sync_check(c);
 }
 
 int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params)
@@ -426,6 +474,14 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
     c->conv.clear();
     c->have_weights = false;
 
+    // per-channel output exponents of the ReLU layers (see pack_conv): the stored activation is y * 2^e with e chosen from the
+    // layer's own BatchNorm so that its typical magnitude (|gamma| + |beta|: z ~ N(beta, gamma^2) under true statistics) is O(1)
+    std::map<std::string, std::vector<int>> out_exps;
+    static const std::map<std::string, std::string> kInputOf = {
+        {"conv1_2", "conv1_1"}, {"conv1_3", "conv1_2"}, {"side_op1", "conv1_3"}, {"conv2_1", "conv1_3"}, {"conv2_2", "conv2_1"},
+        {"conv2_3", "conv2_2"}, {"side_op2", "conv2_3"}, {"conv3_1", "conv2_3"}, {"conv3_2", "conv3_1"}, {"conv3_3", "conv3_2"},
+        {"side_op3", "conv3_3"}, {"conv4_1", "conv3_3"}, {"conv4_2", "conv4_1"}, {"conv4_3", "conv4_2"}, {"side_op4", "conv4_3"},
+        {"merge_conv_b", "merge_conv_a"}, {"merge_conv3", "merge_conv_b"}};     // conv1_1 <- CVC, merge_conv_a <- sigmoid side outputs: exponent 0
     int pi = 0, rc;
     for (int li = 0; li < kNumSpecs; ++li) {
         const LayerSpec &sp = kSpecs[li];
@@ -464,10 +520,15 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
                     for (int t = 0; t < ntap; ++t) Wt[((size_t)o * sp.cin + ci) * ntap + t] = W[((size_t)ci * sp.cout + o) * ntap + t];
             W = Wt.data();
         }
+        const int *in_exp = nullptr;
+        {
+            auto src = kInputOf.find(sp.name);
+            if (src != kInputOf.end()) in_exp = out_exps.at(src->second).data();
+        }
         if (strcmp(sp.name, "merge_conv3") == 0) {
             // fused into merge_conv_b's epilogue in fp32
             std::vector<float> w3(7 * 16 + 16, 0.f);
-            for (int ci = 0; ci < sp.cin; ++ci) w3[ci] = W[ci];
+            for (int ci = 0; ci < sp.cin; ++ci) w3[ci] = std::ldexp(W[ci], -in_exp[ci]);
             if (c->w3) dev_free_owned(c, c->w3);
             if ((rc = dev_alloc(c, &c->w3, w3.size())) != SN_OK) return rc;
             HIPCHK(hipMemcpy(c->w3, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -479,7 +540,14 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
         L.name = sp.name; L.cin = sp.cin; L.cout = sp.cout; L.ks = k; L.dil = (sp.kind == K_DIL3) ? 2 : 1; L.act = sp.act;
         const int lsplit = (c->split == 1 && ((c->tail_m8 >= 1 && L.name == "merge_conv_b") || (c->tail_m8 >= 2 && L.name == "merge_conv_a"))) ? 2 : c->split;   // see run_net_t
         const TileChoice tc = tile_for(sp, lsplit);
-        if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit)) != SN_OK) return rc;
+        std::vector<int> &oe = out_exps[sp.name];
+        oe.assign(sp.cout, 0);
+        if (sp.act == 0)                                     // ReLU layers only: a sigmoid output lies in (0,1) as it is
+            for (int o = 0; o < sp.cout; ++o) {
+                const float m = std::max(std::fabs(gamma[o]), std::fabs(beta[o]));
+                if (m > 0.f && std::isfinite(m)) oe[o] = std::max(-60, std::min(60, -std::ilogb(m)));
+            }
+        if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit, in_exp, oe.data())) != SN_OK) return rc;
         c->conv[L.name] = L;
     }
     c->have_relw = false;
@@ -674,7 +742,7 @@ int sn_forward(sn_ctx *c, int n, int n_vp, const float *X, const float *w, float
         if ((rc = sn_forward_dev(c, m, n_vp, c->d_X, c->d_w, c->d_fused, c->unf_ws)) != SN_OK) return rc;
         HIPCHK(hipMemcpyAsync(fused + (size_t)i0 * s3, c->d_fused, sizeof(float) * s3 * m, hipMemcpyDeviceToHost, c->stream));
         if (unfused) HIPCHK(hipMemcpyAsync(unfused + (size_t)i0 * n_vp * s3, c->unf_ws, sizeof(float) * s3 * m * n_vp, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((rc = sync_check(c)) != SN_OK) return rc;
     }
     return SN_OK;
 }
@@ -705,7 +773,7 @@ int sn_cvc_forward(sn_ctx *c, int n, int n_vp, const int64_t *pairs, const float
         HIPCHK(hipMemcpyAsync(fused + (size_t)i0 * s3, c->d_fused, sizeof(float) * s3 * m, hipMemcpyDeviceToHost, c->stream));
         if (unfused) HIPCHK(hipMemcpyAsync(unfused + (size_t)i0 * n_vp * s3, c->unf_ws, sizeof(float) * s3 * m * n_vp, hipMemcpyDeviceToHost, c->stream));
         if (cvc_out) HIPCHK(hipMemcpyAsync(cvc_out + (size_t)i0 * n_vp * per, c->d_X, sizeof(float) * per * m * n_vp, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((rc = sync_check(c)) != SN_OK) return rc;
     }
     return SN_OK;
 }

@@ -102,6 +102,8 @@ struct sn_ctx {
     std::vector<sn_param_desc> simil_descs;
     void *sws = nullptr; size_t sws_bytes = 0; int sws_n = 0, sws_split = -1;
     // post-pass (ray pooling / dense2sparse) workspace
+    unsigned *d_num = nullptr;    // numeric status word: bit i = conv layer i of the launch order stored a non-finite / fp16-overflowing value
+    std::vector<std::string> num_names;   // layer name of each status bit
     void *rp_ws = nullptr; size_t rp_ws_bytes = 0; int *d_err = nullptr; int *d_counts = nullptr; int d_counts_cap = 0;
     std::vector<void *> owned;
     // profiling
@@ -185,7 +187,7 @@ static int prof_drain(sn_ctx *c)
 
 // Folds BN, packs the weights of one conv layer into MFMA fragment order (defined in sn_api.hip).
 int pack_conv(sn_ctx *c, PackedConv &L, const float *W, const float *beta, const float *gamma, const float *mean,
-              const float *inv_std, int nf, int nsplit, int cs8max, int split);
+              const float *inv_std, int nf, int nsplit, int cs8max, int split, const int *in_exp = nullptr, const int *out_exp = nullptr);
 
 static bool shape_is(const sn_param_desc &d, std::initializer_list<int> s)
 {
@@ -230,6 +232,14 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
             return fail(SN_ERR_ARG, "%s: a %d-group channel slab of a %dx%dx%d volume exceeds the 32 MiB this kernel's halo addressing covers", L.name.c_str(), C::CS8MAX, DX, D, D);
     }
     a.act = L.act;
+    if (c->d_num) {
+        // one status bit per layer name (2-D similarityNet layers share bit 31)
+        auto it = std::find(c->num_names.begin(), c->num_names.end(), L.name);
+        size_t bit = it - c->num_names.begin();
+        if (it == c->num_names.end() && c->num_names.size() < 31) c->num_names.push_back(L.name);
+        a.status = c->d_num;
+        a.status_bit = bit < 31 ? (1u << bit) : (1u << 31);
+    }
     a.nslab = (int)L.slab_c8.size();
     for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
     const double vox = (double)B * DX * D * D;

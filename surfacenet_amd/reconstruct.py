@@ -12,6 +12,9 @@
 * `gather_sparse_sharded`   the multi-GPU exchange when the post-pass runs on the GPU: every rank holds only the packed
                            sparse voxel lists of its cube shard (9 B per kept voxel instead of 4 B x s^3 per cube); two
                            all-gathers (lengths, then one padded byte buffer) rebuild the global lists on every rank
+* `reconstruct_scene_sharded`  the same for a cube list sharded over the ranks of a process group: every stage (early rejection,
+                           view-pair selection, the cube loop) is per-cube, so each rank runs `reconstruct_scene` on its contiguous
+                           cube range and ONE exchange of the packed per-rank results rebuilds the scene's lists on every rank
 * `shard_bounds`, `infer_cubes_sharded`  cubes are independent: contiguous ranges per rank, no data-path
                            collective; ONE all-gather of the fused probabilities at the end (RCCL over xGMI when the
                            process group is "nccl"; gloo on CPU in the tests)
@@ -338,3 +341,79 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
     out["vxl_mask_list"] = sparseCubes.filter_voxels(vxl_mask_list=[], prediction_list=out["prediction_list"], prob_thresh=tau,
                                                      rayPooling_votes_list=out["rayPooling_votes_list"], rayPool_thresh=gamma * N_vp * 2)
     return out
+
+
+def _allgather_bytes(blob, group=None, device=None):
+    """All-gather of one variable-length byte string per rank (np.uint8 1-D): lengths first, then one padded buffer. `device`:
+    where the collective runs (None = CPU tensors for gloo; a CUDA device for RCCL)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = torch.zeros((world,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, torch.tensor([blob.size], dtype=torch.int64, device=device), group=group)
+    cap = max(1, int(sizes.max().item()))
+    buf = torch.zeros((cap,), dtype=torch.uint8, device=device)
+    buf[: blob.size] = torch.from_numpy(np.ascontiguousarray(blob)).to(buf.device)
+    allb = torch.empty((world * cap,), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(allb, buf, group=group)
+    allb = allb.cpu().numpy()
+    return [allb[r * cap: r * cap + int(sizes[r].item())] for r in range(world)]
+
+
+_SCENE_LISTS = ("prediction_list", "rgb_list", "vxl_ijk_list", "rayPooling_votes_list", "vxl_mask_list")
+_SCENE_ROWS = ("patches_embedding", "inScope_cubes_vs_views", "dissimilarity", "validCubes")            # one row per cube of the shard
+_SCENE_VALID_ROWS = ("viewPairs4Reconstr", "w_viewPairs4Reconstr")                                       # one row per VALID cube
+_SCENE_NONEMPTY_ROWS = ("cube_ijk_np", "param_np", "viewPair_np")                                        # one row per non-empty cube
+
+
+def _pack_scene(res):
+    """reconstruct_scene's dict -> one npz byte string (variable-length lists as a concatenation + lengths)."""
+    import io
+    arrs = {}
+    for k in _SCENE_ROWS + _SCENE_VALID_ROWS + _SCENE_NONEMPTY_ROWS:
+        if res.get(k) is not None:
+            arrs[k] = np.asarray(res[k])
+    for k in _SCENE_LISTS:
+        lst = res.get(k) or []
+        arrs[k + "/len"] = np.asarray([len(x) for x in lst], dtype=np.int64)
+        if lst:
+            arrs[k + "/cat"] = np.concatenate([np.asarray(x) for x in lst])
+    f = io.BytesIO()
+    np.savez(f, **arrs)
+    return np.frombuffer(f.getvalue(), dtype=np.uint8)
+
+
+def _merge_scenes(blobs):
+    """Per-rank npz byte strings (rank order = cube order) -> one reconstruct_scene dict."""
+    import io
+    parts = [np.load(io.BytesIO(b.tobytes()), allow_pickle=False) for b in blobs]
+    out = {}
+    for k in _SCENE_ROWS + _SCENE_VALID_ROWS + _SCENE_NONEMPTY_ROWS:
+        have = [p[k] for p in parts if k in p.files]
+        out[k] = np.concatenate(have, axis=0) if have else None
+    for k in _SCENE_LISTS:
+        out[k] = []
+        for p in parts:
+            lens = p[k + "/len"]
+            if lens.size:
+                cat, ends = p[k + "/cat"], np.cumsum(lens)
+                out[k].extend(cat[e - n: e] for n, e in zip(lens, ends))
+    return out
+
+
+def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, *args, **kwargs):
+    """`reconstruct_scene` for a cube list sharded over the ranks of a torch.distributed process group (one process per GPU).
+
+    Early rejection, view-pair selection, the cube loop and the thinning mask are all per-cube, and weights / images / cameras are
+    replicated, so rank r runs the whole single-GPU pipeline on its contiguous cube range `shard_bounds(N_cubes, world, r)` with
+    no data-path collective; at the end ONE exchange of each rank's packed result (sparse voxel lists: 9 B per kept voxel; per-cube
+    rows: embeddings, dissimilarities, selections) rebuilds on every rank exactly the dict `reconstruct_scene` returns for all
+    cubes (rank order = cube order). Keywords beside reconstruct_scene's: `group` (process group), `comm_device` (None: CPU tensors,
+    e.g. gloo; a CUDA device for RCCL), `shard_fn` (the per-shard pipeline; default `reconstruct_scene`)."""
+    import torch.distributed as dist
+    group, comm_device = kwargs.pop("group", None), kwargs.pop("comm_device", None)
+    shard_fn = kwargs.pop("shard_fn", None) or reconstruct_scene
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(len(cubes_param_np), world, rank)
+    res = shard_fn(images_list, cameraPOs_np, cubes_param_np[lo:hi], *args, **kwargs)
+    return _merge_scenes(_allgather_bytes(_pack_scene(res), group=group, device=comm_device))

@@ -94,3 +94,85 @@ def test_sparse_lists_exchange_gloo(n):
         for k in (1, 2, 3, 4):
             assert len(full[k]) == len(want[k]) and all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(full[k], want[k])), k
         assert np.array_equal(full[5], want[5])
+
+
+PARAM_DT = [("xyz", np.float32, (3,)), ("ijk", np.uint32, (3,)), ("resol", np.float32)]
+
+
+def _fake_scene(images_list, cameraPOs_np, cubes, *a, **kw):
+    """Stand-in for the per-shard GPU pipeline with reconstruct_scene's return contract: everything is a deterministic function of
+    the cube's 'ijk' tag, so a sharded run must reproduce the one-piece run bit for bit. Cube g is rejected when g % 4 == 3 and
+    yields no voxels when g % 5 == 0."""
+    g = cubes["ijk"][:, 0].astype(np.int64)
+    n, V, N_vp = len(cubes), 3, 2
+    rs = lambda i: np.random.RandomState(int(i))
+    emb = np.stack([rs(i).rand(V, 8).astype(np.float32) for i in g]) if n else np.zeros((0, V, 8), np.float32)
+    valid = (g % 4) != 3
+    out = dict(patches_embedding=emb, inScope_cubes_vs_views=(emb[:, :, 0] > 0.2), dissimilarity=emb[:, :, 1].copy(), validCubes=valid,
+               prediction_list=[], rgb_list=[], vxl_ijk_list=[], rayPooling_votes_list=[], cube_ijk_np=None, param_np=None, viewPair_np=None,
+               vxl_mask_list=[])
+    if not valid.any():
+        return out
+    gv = g[valid]
+    out["viewPairs4Reconstr"] = np.stack([rs(100 + i).randint(0, V, (N_vp, 2)) for i in gv])
+    out["w_viewPairs4Reconstr"] = np.stack([rs(200 + i).rand(N_vp).astype(np.float32) for i in gv])
+    keep = [j for j, i in enumerate(gv) if i % 5]
+    for j in keep:
+        i, k = gv[j], int(gv[j] % 7) + 1
+        out["prediction_list"].append(rs(300 + i).rand(k).astype(np.float16)); out["rgb_list"].append(rs(400 + i).randint(0, 256, (k, 3)).astype(np.uint8))
+        out["vxl_ijk_list"].append(rs(500 + i).randint(0, 26, (k, 3)).astype(np.uint8)); out["rayPooling_votes_list"].append(rs(600 + i).randint(0, 5, k).astype(np.uint8))
+        out["vxl_mask_list"].append(rs(700 + i).rand(k) > 0.5)
+    sub = cubes[valid][keep]
+    out.update(param_np=sub, cube_ijk_np=sub["ijk"], viewPair_np=out["viewPairs4Reconstr"].astype(np.uint16)[keep])
+    return out
+
+
+def _scene_cubes(n):
+    cubes = np.zeros((n,), dtype=PARAM_DT)
+    cubes["ijk"][:, 0] = np.arange(n)
+    cubes["xyz"] = np.arange(n, dtype=np.float32)[:, None] * 0.5
+    cubes["resol"] = 0.4
+    return cubes
+
+
+def _scene_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from surfacenet_amd import reconstruct
+    import test_dist_cpu as T
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = reconstruct.reconstruct_scene_sharded([], np.zeros((3, 3, 4)), T._scene_cubes(n), shard_fn=T._fake_scene)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def _same_scene(a, b):
+    for k in ("patches_embedding", "inScope_cubes_vs_views", "dissimilarity", "validCubes", "viewPairs4Reconstr", "w_viewPairs4Reconstr",
+              "cube_ijk_np", "param_np", "viewPair_np"):
+        x, y = a.get(k), b.get(k)
+        assert (x is None) == (y is None), k
+        assert x is None or (np.array_equal(x, y) and x.dtype == y.dtype), k
+    for k in ("prediction_list", "rgb_list", "vxl_ijk_list", "rayPooling_votes_list", "vxl_mask_list"):
+        assert len(a[k]) == len(b[k]) and all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(a[k], b[k])), k
+
+
+@pytest.mark.parametrize("n", [11, 3, 1])
+def test_sharded_scene_equals_one_piece_gloo(n):
+    """reconstruct_scene_sharded over 2 ranks (contiguous cube shards, one exchange of the packed results) == the one-piece run;
+    n = 1 leaves rank 1 with an empty shard, n = 3 gives rank 1 a shard whose only cube is rejected / empty."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_scene_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _fake_scene([], None, _scene_cubes(n))
+    for rank, full in res:
+        _same_scene(full, want)
