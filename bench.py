@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--n-vp", type=int, default=2)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x3p", "f16m8", "f16"],
                     help="f16x3 (default): hi/lo split fp16 operands, fp32-class results (parity grade); f16: fast mode, L_inf ~2e-3")
+    ap.add_argument("--native-comm", action="store_true", help="N>1: all-gather through the library's own RCCL binding (sn_comm_init / sn_allgather_f32_dev, "
+                    "in-order on the context's stream) instead of torch.distributed's; torch.distributed still carries the 128-byte id and the barriers")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16 fast-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-s64", action="store_true", help="skip the extra s=64 measurement")
@@ -268,7 +270,17 @@ def main():
     ctx.set_cameras(scene["cams"])
     ctx.set_images(scene["imgs"])
     d_pairs, d_xyz, d_resol, d_w = (ctx.upload(scene[k]) for k in ("pairs", "xyz", "resol", "w"))
-    if use_dist:
+    native = use_dist and (args.native_comm or bool(os.environ.get("BENCH_NATIVE_COMM")))
+    if native:
+        # the C ABI's own exchange: rank 0 draws the RCCL unique id, torch.distributed ships its 128 bytes, every rank joins
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(surfacenet_amd.Context.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        d_fused = [ctx.dev_alloc(n * s3 * 4) for _ in range(2)]
+        d_all = [ctx.dev_alloc(world * n * s3 * 4) for _ in range(2)]
+    elif use_dist:
         # Double-buffered and host-sync free: the all-gather of step i (torch's stream) overlaps the kernels of step i+1 (the
         # context's stream); the two streams are ordered against each other with events only.
         t_fused = [torch.empty(n * s3, dtype=torch.float32, device="cuda") for _ in range(2)]
@@ -284,6 +296,10 @@ def main():
     def step():
         b = step_no[0] & 1
         step_no[0] += 1
+        if native:
+            ctx.cvc_forward_dev(n, n_vp, d_pairs, d_xyz, d_resol, d_w, d_fused[b])
+            ctx.allgather_f32_dev(d_fused[b], n * s3, d_all[b])            # RCCL, in order on the context's stream
+            return
         if use_dist and gathered[b] is not None:
             sn_stream.wait_event(gathered[b])      # the all-gather that read this buffer two steps ago must be done first
         ctx.cvc_forward_dev(n, n_vp, d_pairs, d_xyz, d_resol, d_w, d_fused[b])
@@ -339,7 +355,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": "synthetic 2-view 1600x1200, s=%d, batch=%d cubes/GPU, N_viewpair=%d (BASELINE.json configs[1])" % (s, n, n_vp),
-                       "cubes_per_gpu": n, "samples_per_step": n * n_vp * world, "parallelism": "cube-sharded x%d%s" % (world, ", RCCL all-gather of fused probabilities" if world > 1 else "")},
+                       "cubes_per_gpu": n, "samples_per_step": n * n_vp * world, "parallelism": "cube-sharded x%d%s" % (world, (", RCCL all-gather of fused probabilities" + (" (native sn_allgather_f32_dev)" if native else " (torch.distributed)")) if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": "conv3d_f16_mfma<%s>" % dom, "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                          "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],

@@ -16,6 +16,9 @@ Accommodations for Python 3 (numbers are unaffected): scene.py's module-level im
 unused by initializeCubes) are satisfied by empty stand-in modules; `cubes_ijk.size / 3` (scene.py:53, py2 integer division)
 is executed as `//`. No reference source text is written anywhere; only numbers.
 
+Also writes surfacenet_amd/data/calibration.npz: the same P matrices and bounding boxes (dataset calibration data only), which
+tools/bench_scene.py and bench.py's scene legs read on the GPU box.
+
 Usage:  python oracle/gen_golden_scene.py   (from the repo root)
 """
 import contextlib
@@ -95,6 +98,10 @@ def main():
         # executed here, starts at BB_min - 6 = [-3, -17, -116]; only `cube_D_mm == 22` of that doctest still holds)
         assert dmm == 22 and np.array_equal(cubes["xyz"][0], [-3, -17, -116])
     np.savez_compressed(os.path.join(OUT, "scene_cases.npz"), **out)
+    # the calibration numbers alone (dataset data, no expected outputs) also ship with the package, for the scene benches
+    data_dir = os.path.join(os.path.dirname(OUT), "..", "surfacenet_amd", "data")
+    os.makedirs(data_dir, exist_ok=True)
+    np.savez(os.path.join(data_dir, "calibration.npz"), P_dtu49=out["P_dtu49"], P_mid16=out["P_mid16"], scan9_BB=out["scan9_BB"], dino_BB=out["dino_BB"])
     print("scene_cases.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith("_n") or k.endswith("_grid") or k.startswith("P_")})
     print({k: out[k] for k in out if k.endswith("_n") or k.endswith("_grid") or k.endswith("_cube_D_mm")})
 

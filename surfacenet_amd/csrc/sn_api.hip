@@ -884,6 +884,7 @@ int sn_color_fuse(sn_ctx *c, int n, int n_vp, const float *cvc, const float *mea
 namespace {
 struct Rccl {
     void *h = nullptr;
+    int version = 0;                              // ncclGetVersion code (major*10000 + minor*100 + patch)
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, const char (*)[128], int) = nullptr;   // real ABI passes the 128-byte struct by value
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
@@ -906,6 +907,15 @@ int rccl_load()
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
         return fail(SN_ERR_COMM, "librccl lacks an expected symbol");
+    // The five entry points above are bound through hand-written prototypes (no rccl.h dependency at build time): they are
+    // the NCCL 2.x ABI (ncclUniqueId = 128 bytes by value, ncclDataType_t ncclFloat32 = 7). Refuse anything else.
+    int (*get_version)(int *) = (int (*)(int *))dlsym(h, "ncclGetVersion");
+    int ver = 0;
+    if (!get_version || get_version(&ver) != 0 || ver < 20000 || ver >= 30000) {
+        dlclose(h);
+        return fail(SN_ERR_COMM, "librccl reports version code %d: this library binds the NCCL 2.x ABI only", ver);
+    }
+    g_rccl.version = ver;
     g_rccl.h = h;
     return SN_OK;
 }

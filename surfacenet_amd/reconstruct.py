@@ -281,14 +281,24 @@ def gather_sparse_sharded(local, lo, group=None, device=None):
 def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, patch2embedding_fn,
                       embeddingPair2simil_fn, viewPair_relativeImpt_fn, cube_Dcenter, patches_mean_bgr, batchSize_similNet_patch2embedding=100,
                       batchSize_similNet_embeddingPair2simil=100000, batchSize_viewPair_w=100000, batchSize_nViewPair_SurfaceNet=None,
-                      weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64, ctx=None):
+                      weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64, ctx=None, timings=None):
     """The body of main_reconstruct.reconstruction() between file input and PLY output (main_reconstruct.py:67-173):
     corner / centre projections -> early rejection (similarityNet) -> view-pair selection (relative-weight MLP) ->
     per batch: CVC, SurfaceNet, fusion, voxel colours, ray pooling, dense2sparse -> thinning masks.
     The three *_fn arguments are the callables of similarityNet.similarityNet_inference / SurfaceNet.SurfaceNet_inference
     (their weights are bound in `runtime`). Returns a dict with the reference's variable names. Not included (SURVEY §2.1,
-    out of scope): image / camera readers, cube tiling, cross-cube denoising, PLY / npz writers."""
+    out of scope): image / camera readers, cube tiling, cross-cube denoising, PLY / npz writers.
+    `timings` (optional dict) receives the wall seconds of every stage."""
+    import time
     from . import camera, earlyRejection, runtime, sparseCubes, viewPairSelection
+    clock = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - clock[0])
+            clock[0] = now
+
     cameraPOs_np = np.asarray(cameraPOs_np, dtype=np.float64)
     N_vp = int(N_viewPairs4inference)
     # main_reconstruct.py:67-71
@@ -298,15 +308,18 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
                                                                   return_int_hw=False, return_depth=False)
     N_views, N_cubes = img_h_cubesCorner.shape[:2]
     cameraTs_np = viewPairSelection.camera_centers(cameraPOs_np)                                    # main_reconstruct.py:50
+    lap("projections")
     # :84-97 early rejection
     viewPairs = viewPairSelection.k_combination_np(range(N_views), k=2)
     patches_embedding, inScope_cubes_vs_views = earlyRejection.patch2embedding(
         images_list, img_h_cubesCorner, img_w_cubesCorner, patch2embedding_fn, patches_mean_bgr, N_cubes, N_views, D_embedding, patchSize=patchSize,
         batchSize=batchSize_similNet_patch2embedding, cubeCenter_hw=np.stack([img_h_cubesCenter, img_w_cubesCenter], axis=0))
+    lap("patch2embedding")
     dissimilarity = earlyRejection.embeddingPairs2simil(embeddings=patches_embedding, embeddingPair2simil_fn=embeddingPair2simil_fn,
                                                         inScope_cubes_vs_views=inScope_cubes_vs_views, viewPairs=viewPairs, N_views=N_views,
                                                         batchSize=batchSize_similNet_embeddingPair2simil)
     validCubes = earlyRejection.selectFromSimilarity(dissimilarityProb=dissimilarity, N_viewPairs4inference=N_vp)
+    lap("pair_similarity")
     out = dict(patches_embedding=patches_embedding, inScope_cubes_vs_views=inScope_cubes_vs_views, dissimilarity=dissimilarity, validCubes=validCubes,
                prediction_list=[], rgb_list=[], vxl_ijk_list=[], rayPooling_votes_list=[], cube_ijk_np=None, param_np=None, viewPair_np=None,
                vxl_mask_list=[])
@@ -320,6 +333,7 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
     if weighted_fusion is False:
         w_viewPairs4Reconstr[:] = 1.0 / N_vp
     out.update(viewPairs4Reconstr=viewPairs4Reconstr, w_viewPairs4Reconstr=w_viewPairs4Reconstr)
+    lap("viewpair_selection")
     # :126-166 the cube-batch loop, device-resident
     ctx = ctx or runtime.context_for(cube_D)
     runtime.bind_scene(ctx, cameraPOs_np, images_list)
@@ -333,6 +347,7 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
                                                                   cubes_param_np['resol'][validCubes], w_viewPairs4Reconstr)
     finally:
         loop.close()
+    lap("cube_loop")
     param_sub = np.copy(cubes_param_np[validCubes])
     param_sub['xyz'] = xyz_new
     out.update(prediction_list=p_l, rgb_list=rgb_l, vxl_ijk_list=ijk_l, rayPooling_votes_list=v_l, param_np=param_sub[nonempty],
@@ -340,6 +355,7 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
     # :172-173 thinning
     out["vxl_mask_list"] = sparseCubes.filter_voxels(vxl_mask_list=[], prediction_list=out["prediction_list"], prob_thresh=tau,
                                                      rayPooling_votes_list=out["rayPooling_votes_list"], rayPool_thresh=gamma * N_vp * 2)
+    lap("thinning")
     return out
 
 

@@ -257,3 +257,67 @@ def test_two_contexts_and_precision_switch_are_independent(sn):
         c2.load_param_values(values)
         fc, _ = c2.forward(X8, None, n_vp=1)
     assert 0 < np.abs(fc - fa1).max() < 1e-2                               # f16 differs from f16x3, by a little
+
+
+@pytest.mark.parametrize("n,n_vp", [(14, 5), (3, 16)])
+def test_forward_at_reference_operating_points(sn, n, n_vp):
+    """The reference's own settings: N_viewPairs4inference = 5 (DTU, params.py:165) with its default batch of 14 cubes at s=32
+    (params.py:117-118: floor(1.2 * 12 GB)) and 16 view pairs (BASELINE configs[4]); s = 16 keeps the fp64 oracle affordable.
+    Through the fused entry (CVC warp on 3 views -> CNN -> weighted fusion) with un-normalised top-N style weights."""
+    from oracle import cvc_oracle, net_oracle
+    import synth
+    from surfacenet_amd import synthetic
+    s = 16
+    cams = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "scene_cases.npz"))["P_dtu49"][[0, 1, 7]].copy()
+    cams[:, :2, :] *= 0.5
+    sc = synthetic.synthetic_scene(n, n_vp, s=s, seed=40 + n_vp, hw=(600, 800), cams=cams)
+    sc["w"] = (np.sort(np.random.RandomState(n_vp).rand(n, n_vp), axis=1) * 0.2).astype(np.float32)     # ascending, not summing to 1 (viewPairSelection.py:38)
+    values = list(synth.calibrated_params(2))
+    with sn.Context(cube_D=s, max_samples=n * n_vp) as ctx:
+        ctx.load_param_values(values)
+        ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        fused, unfused, cvc = ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"], sc["w"], return_cvc=True)
+    with sn.Context(cube_D=s, max_samples=8) as ctx:                       # the same through a workspace that forces ragged chunks (8 // n_vp cubes)
+        ctx.load_param_values(values)
+        ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        if n_vp <= 8:
+            f2, u2, _ = ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"], sc["w"])
+            assert np.array_equal(f2, fused) and np.array_equal(u2, unfused)
+        else:
+            with pytest.raises(sn.SurfaceNetHipError):                     # one cube's view pairs must fit the workspace
+                ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"], sc["w"])
+    ref_cvc = cvc_oracle.gen_coloredCubes(sc["pairs"], sc["xyz"], sc["resol"], sc["cams"], sc["imgs"], s, mean6=golden_util.MEAN6)
+    assert np.array_equal(cvc, ref_cvc)
+    f64, u64 = net_oracle.forward_torch(ref_cvc, values, w=sc["w"], n_vp=n_vp)
+    assert unfused.shape == (n, n_vp, s, s, s) and fused.shape == (n, 1, s, s, s)
+    e_u, e_f = np.abs(unfused - u64).max(), np.abs(fused - f64).max()
+    print("n=%d n_vp=%d: L_inf unfused %.3e fused %.3e" % (n, n_vp, e_u, e_f))
+    assert e_u < TOL_X3 and e_f < TOL_X3
+
+
+def test_hot_loop_reference_batching_31_cubes_batch_14(sn):
+    """main_reconstruct.py:126-146 with the reference's batch size 14 on 31 valid cubes of 40 (batches of 14, 14 and a ragged 3;
+    utils/utils.py:106-109), N_vp = 5: every valid cube exactly once, each batch equal to the one-shot result."""
+    import synth
+    from surfacenet_amd import reconstruct, synthetic
+    s, n_all, n_vp = 8, 40, 5
+    rs = np.random.RandomState(5)
+    validCubes = np.ones(n_all, dtype=bool)
+    validCubes[rs.choice(n_all, 9, replace=False)] = False
+    cams = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "scene_cases.npz"))["P_dtu49"][:5].copy()
+    cams[:, :2, :] *= 0.25
+    sc = synthetic.synthetic_scene(n_all, n_vp, s=s, seed=9, hw=(300, 400), cams=cams)
+    cubes = np.zeros(n_all, dtype=synthetic.CUBE_DTYPE)
+    cubes["xyz"], cubes["resol"] = sc["xyz"], sc["resol"]
+    vp4, w4 = sc["pairs"][validCubes], sc["w"][validCubes]
+    values = list(synth.calibrated_params(0))
+    with sn.Context(cube_D=s, max_samples=14 * n_vp) as ctx:
+        ctx.load_param_values(values); ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        whole_f, whole_u, _ = ctx.cvc_forward(vp4, cubes["xyz"][validCubes], cubes["resol"][validCubes], w4)
+        sizes, seen, pos = [], np.zeros(n_all, int), 0
+        for _batch, pred, unf, _ in reconstruct.hot_loop(ctx, validCubes, vp4, w4, cubes, batch_size=14, return_cvc=False):
+            k = int(_batch.sum())
+            sizes.append(k); seen += _batch
+            assert np.array_equal(pred, whole_f[pos:pos + k]) and np.array_equal(unf, whole_u[pos:pos + k])
+            pos += k
+    assert sizes == [14, 14, 3] and np.array_equal(seen, validCubes.astype(int))

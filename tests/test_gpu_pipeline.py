@@ -77,3 +77,72 @@ def test_reconstruct_scene_equals_reference_style_script(gpu_required):
     assert np.array_equal(res["param_np"]["xyz"], param_np["xyz"]) and np.array_equal(res["param_np"]["resol"], param_np["resol"])
     assert sum(int(m.sum()) for m in masks) > 0
     runtime.reset()
+
+
+def _pipeline_inputs():
+    """A small synthetic scene on the DTU rig: 4 views, 12 cubes (one projects outside every view), synthetic nets."""
+    import synth
+    from surfacenet_amd import weights
+    cube_D, Dc, N_vp, resol = 16, 12, 2, np.float32(0.8)
+    P = golden_util.cameras()["P_dtu"][:4].copy()
+    P[:, :2, :] *= 0.5
+    imgs = [golden_util.synth_image(900 + v, 600, 800) for v in range(4)]
+    rs = np.random.RandomState(3)
+    N_cubes = 12
+    cubes = np.empty((N_cubes,), dtype=PARAM_DT)
+    cubes["xyz"] = (rs.rand(N_cubes, 3) * [80, 80, 40] + [-40, -40, 590]).astype(np.float32)
+    cubes["xyz"][5] = [2000, 2000, 100]
+    cubes["ijk"] = rs.randint(0, 40, (N_cubes, 3))
+    cubes["resol"] = resol
+    simil_values = weights.synthetic_simil_param_values(6)
+    simil_values[28][:] = 3.0; simil_values[29][:] = -2.5
+    return dict(cube_D=cube_D, Dc=Dc, N_vp=N_vp, cube_D_mm=resol * cube_D, P=P, imgs=imgs, cubes=cubes, net_values=list(synth.calibrated_params(1)),
+                simil_values=simil_values)
+
+
+def _run_scene(inp, sharded):
+    from surfacenet_amd import SurfaceNet, reconstruct, runtime, similarityNet
+    runtime.reset()
+    p2e, pair_fn = similarityNet.similarityNet_inference(None, (64, 64), param_values=inp["simil_values"])
+    relw_fn, _ = SurfaceNet.SurfaceNet_inference(inp["N_vp"], None, None, cube_D=inp["cube_D"], param_values=inp["net_values"])
+    fn = reconstruct.reconstruct_scene_sharded if sharded else reconstruct.reconstruct_scene
+    res = fn(inp["imgs"], inp["P"], inp["cubes"], inp["cube_D_mm"], inp["cube_D"], inp["N_vp"], p2e, pair_fn, relw_fn, cube_Dcenter=inp["Dc"],
+             patches_mean_bgr=MEAN_BGR, batchSize_nViewPair_SurfaceNet=4, min_prob=0.5, tau=0.6, gamma=0.5)
+    runtime.reset()
+    return res
+
+
+def _sharded_worker(rank, world, port, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    import test_gpu_pipeline as T
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share the box's one GPU; the exchange runs on gloo
+    res = T._run_scene(T._pipeline_inputs(), sharded=True)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_sharded_scene_two_processes_equals_single_process(gpu_required):
+    """reconstruct_scene_sharded with 2 ranks (two processes on this box's GPU, cube shards 0-5 / 6-11, gloo exchange) returns on
+    every rank exactly what the single-process reconstruct_scene returns - GPU kernels on both sides."""
+    import os
+    import torch.multiprocessing as mp
+    import test_dist_cpu
+    want = _run_scene(_pipeline_inputs(), sharded=False)
+    assert want["validCubes"].sum() > 0 and len(want["prediction_list"]) > 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, full in res:
+        test_dist_cpu._same_scene(full, want)
