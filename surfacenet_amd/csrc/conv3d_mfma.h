@@ -80,6 +80,14 @@ struct ConvArgs {
     const float *shift;
     const float *w3;      // EPI_FINAL: [NF*16] fp32 weights of the fused 1x1x1 conv
     const void *zero_page;    // >= 16 zero bytes: source of out-of-volume / padding voxels (generic halo path of the 2-D nets)
+    // EPI_SIDEPOOL: packed A fragments of the 1x1x1 side conv [(NF+1)/2 K-chunks][hi | lo][64 lanes][8 halfs], its folded BN, and the two
+    // destinations: side output -> channels [side_coff, side_coff+16) of a [B][side_cs/8][D]^3[8] tensor (format OSPLIT),
+    // pooled output -> [B][pool_cs/8][D/2]^3[8] (format SPLIT)
+    const _Float16 *side_w;
+    const float *side_scale, *side_shift;
+    _Float16 *side_out, *pool_out;
+    long long side_lo_off, pool_lo_off;
+    int side_cs, side_coff, pool_cs, side_act;
     unsigned *status;         // numeric status word of the context (or nullptr): status_bit is OR-ed in when an output value is not
     unsigned status_bit;      // finite or exceeds the fp16 range its hi plane is stored in (|y| > 65504)
     float scale3, shift3;
@@ -94,7 +102,9 @@ struct ConvArgs {
     unsigned char slab_c8[kMaxSlab];  // 8-channel groups per slab
 };
 
-enum { EPI_STORE = 0, EPI_FINAL = 1, EPI_POOL2D = 2 };   // POOL2D (2-D nets): store epilogue fused with the 2x2 max-pool that follows
+enum { EPI_STORE = 0, EPI_FINAL = 1, EPI_POOL2D = 2, EPI_SIDEPOOL = 3 };   // POOL2D (2-D nets): store epilogue fused with the 2x2 max-pool that follows;
+// SIDEPOOL (3-D nets): the layer's own output is never stored - its two consumers, the 1x1x1 side convolution (+BN+sigmoid, one more
+// MFMA chain on the in-register outputs) and the 2x2x2 max-pool, run in the epilogue and store THEIR outputs (nets/SurfaceNet.py:37-38,46-47)
 
 __device__ __forceinline__ float sn_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -264,7 +274,7 @@ conv3d_f16_mfma(ConvArgs a)
     constexpr int HT = (C::NSEG * NPL + C::NW - 1) / C::NW;   // halo DMA instructions per wave and slab
     constexpr int FULLP = ((C::NTAP * C::CS8MAX + 3) / 4 + C::PCH - 1) / C::PCH;      // weight pieces of a full channel slab
     // halo DMA instalment per piece (generic path); the buffer path issues its whole (cheap) set behind the first weight piece of a slab
-    constexpr int HQ = (K2D == 0) ? HT : (FULLP > 1 ? (HT + FULLP - 2) / (FULLP - 1) : HT);
+    constexpr int HQ = (K2D == 0 || FULLP <= 1) ? HT : (HT + FULLP - 2) / (FULLP > 1 ? FULLP - 1 : 1);
     auto stage_halo = [&](int t, int c0, int c8n, int xb, int k0, int kn) -> int {
         int b, x0, y0, z0;
         tile_origin(t, b, x0, y0, z0);
@@ -378,10 +388,21 @@ conv3d_f16_mfma(ConvArgs a)
     // K-chunks the weight STREAM holds for a slab (f16m8 pads every slab to whole pieces)
     auto wchunks_of = [&](int c8n) { return SPLIT == 2 ? (((C::NTAP * c8n + 7) >> 3) << 1) : ((C::NTAP * c8n + 3) >> 2); };
 
+    // Position of voxel fragment m's lane inside the workgroup's output tile. Default: wave w owns x-slices [w*XS, (w+1)*XS), a fragment is
+    // 2 y-rows x 8 z. PMAP (EPI_SIDEPOOL): wave w owns x in {2(w&3), 2(w&3)+1} x 4 y-rows, so that every 2x2x2 pooling cell lies inside ONE
+    // wave (x partner = fragment m+2, y partner = lane^8, z partner = lane^1).
+    constexpr bool PMAP = (EPI == EPI_SIDEPOOL);
+    static_assert(!PMAP || (MF == 4 && NW_ == 8 && K2D == 0), "EPI_SIDEPOOL: 8 waves x 4 fragments over an 8x8x8 tile");
+    auto frag_xyz = [&](int m, int &hx, int &hy, int &hz) {
+        if constexpr (C::F4) { hx = wave * MF + m; hy = v >> 2; hz = v & 3; }
+        else if constexpr (PMAP) { hx = 2 * (wave & 3) + (m >> 1); hy = 4 * (wave >> 2) + 2 * (m & 1) + (v >> 3); hz = v & 7; }
+        else { hx = wave * C::XS + (m >> 2); hy = 2 * (m & 3) + (v >> 3); hz = v & 7; }
+    };
     int xbase[MF];
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-        const int hx = C::F4 ? wave * MF + m : wave * C::XS + (m >> 2), hy = C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3), hz = C::F4 ? (v & 3) : (v & 7);
+        int hx, hy, hz;
+        frag_xyz(m, hx, hy, hz);
         xbase[m] = ((hx * C::HY + hy) * C::HZ + hz) * C::VS;
     }
     const unsigned xbuf_a = lds_addr(xbuf), wbuf_a = lds_addr(wbuf) + lane * 16, kbuf_a = lds_addr(kbuf) + kq * 4;
@@ -391,6 +412,17 @@ conv3d_f16_mfma(ConvArgs a)
             cst[i] = a.scale[blockIdx.y * NF * 16 + i];
             cst[NF * 16 + i] = a.shift[blockIdx.y * NF * 16 + i];
         }
+    // EPI_SIDEPOOL: the side conv's A fragments stay in registers for the whole kernel (K order = the order in which a lane's accumulator
+    // registers hold the channels: k = 8*kq + j <-> channel 16*(2q + (j >= 4)) + 4*kq + (j & 3) of K-chunk q; packed accordingly on the host)
+    constexpr int NQ = (NF + 1) / 2;
+    half8 sw[EPI == EPI_SIDEPOOL ? NQ : 1][2];
+    if constexpr (EPI == EPI_SIDEPOOL) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            sw[q][0] = *reinterpret_cast<const half8 *>(a.side_w + ((size_t)(q * 2 + 0) * 64 + lane) * 8);
+            sw[q][1] = *reinterpret_cast<const half8 *>(a.side_w + ((size_t)(q * 2 + 1) * 64 + lane) * 8);
+        }
+    }
     // ---- prologue: first halo tile, its tap table, first weight piece ----------------------------------------
     {
         const int c8n = a.slab_c8[0];
@@ -676,6 +708,150 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (OSPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
                         if constexpr (OSPLIT == 2) {
                             char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.out_lo_off);
+                            *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                            *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                        }
+                    }
+                }
+            }
+        } else if constexpr (EPI == EPI_SIDEPOOL) {
+            static_assert(NF * 16 <= 96, "side conv K chunks");
+            const int Do = D >> 1;
+            const size_t VOLo = (size_t)Do * Do * Do;
+            // this layer's outputs, in registers: y[m][n][r] = ReLU(BN(acc)), fp32
+            float y[MF][NF][4];
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                const int nl = n * 16 + kq * 4;
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f);
+                        bad |= !(t <= kF16Max);
+                        y[m][n][r] = t;
+                    }
+            }
+            // ---- side conv (1x1x1 over all NF*16 channels) on the matrix cores: B operand = the outputs as this lane holds them
+            f32x4 sacc[MF];
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                sacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    half8 bh, bl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = 2 * q + (j >> 2);
+                        const float t = n < NF ? y[m][n < NF ? n : 0][j & 3] : 0.f;
+                        bh[j] = (_Float16)t;
+                        bl[j] = (_Float16)(t - (float)bh[j]);
+                    }
+                    if constexpr (SPLIT != 0) {
+                        sacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw[q][1], bh, sacc[m], 0, 0, 0);
+                        sacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw[q][0], bl, sacc[m], 0, 0, 0);
+                    }
+                    sacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw[q][0], bh, sacc[m], 0, 0, 0);
+                }
+            }
+            // ---- side output: BN + activation, fragment pairs exchanged so that every lane stores one 16-byte group (as EPI_STORE)
+            {
+                const bool odd = kq & 1;
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 ssc = *reinterpret_cast<const f32x4 *>(a.side_scale + kq * 4);
+                const f32x4 ssh = *reinterpret_cast<const f32x4 *>(a.side_shift + kq * 4);
+#pragma unroll
+                for (int mp = 0; mp < MF; mp += 2) {
+                    bool valid[2];
+                    size_t vlin[2];
+                    unsigned hw[2][2], lw[2][2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        int hx, hy, hz;
+                        frag_xyz(mp + e, hx, hy, hz);
+                        const int gx = x0 + hx, gy = y0 + hy, gz = z0 + hz;
+                        valid[e] = gx < DX && gy < D && gz < D;
+                        vlin[e] = ((size_t)gx * D + gy) * D + gz;
+                        half4 h, l;
+                        float lo32[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = sacc[mp + e][r] * ssc[r] + ssh[r];
+                            t = a.side_act == 0 ? fmaxf(t, 0.f) : sn_sigmoid(t);
+                            bad |= !(t <= kF16Max);
+                            if constexpr (OSPLIT == 1) {
+                                _Float16 hh, ll;
+                                sn_split(t, hh, ll);
+                                h[r] = hh; l[r] = ll;
+                            } else {
+                                h[r] = (_Float16)t;
+                                lo32[r] = (t - (float)h[r]) * 4096.f;
+                            }
+                        }
+                        const uint2 hb = __builtin_bit_cast(uint2, h);
+                        hw[e][0] = hb.x; hw[e][1] = hb.y;
+                        if constexpr (OSPLIT == 1) {
+                            const uint2 lb = __builtin_bit_cast(uint2, l);
+                            lw[e][0] = lb.x; lw[e][1] = lb.y;
+                        } else if constexpr (OSPLIT == 2) {
+                            lw[e][0] = (unsigned)sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                            lw[e][1] = (unsigned)sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                        }
+                    }
+                    const bool st = odd ? valid[1] : valid[0];
+                    const size_t my_vlin = odd ? vlin[1] : vlin[0];
+                    const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
+                    const auto h1 = __builtin_amdgcn_permlane16_swap(hw[0][1], hw[1][1], false, false);
+                    const int ch = a.side_coff + ((kq * 4) & ~7);
+                    _Float16 *o = a.side_out + (size_t)b * VOL * a.side_cs + ((size_t)(ch >> 3) * VOL + my_vlin) * 8;
+                    if (st) *reinterpret_cast<u32x4 *>(o) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+                    if constexpr (OSPLIT == 1) {
+                        const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
+                        const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
+                        if (st) *reinterpret_cast<u32x4 *>(o + a.side_lo_off) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+                    } else if constexpr (OSPLIT == 2) {
+                        const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
+                        const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
+                        if (st) *reinterpret_cast<u32x4 *>(o + a.side_lo_off) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                    }
+                }
+            }
+            // ---- 2x2x2 max-pool in registers: x partner = fragment mm+2, y partner = lane ^ 8, z partner = lane ^ 1; stored in the layer's
+            // own format (max(split(y)) == split(max(y)): the hi/lo rounding is monotone, so this equals pooling the stored tensor)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                int hx, hy, hz;
+                frag_xyz(mm, hx, hy, hz);
+                const int gx = x0 + hx, gy = y0 + hy, gz = z0 + hz;
+                const bool writer = !(v & 1) && !(v & 8) && gx < DX && gy < D && gz < D;     // D even: the whole cell is inside
+                const size_t vlin = ((size_t)(gx >> 1) * Do + (gy >> 1)) * Do + (gz >> 1);
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    half4 h, l;
+                    float lo32[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = fmaxf(y[mm][n][r], y[mm + 2][n][r]);
+                        t = fmaxf(t, __shfl_xor(t, 8));
+                        t = fmaxf(t, __shfl_xor(t, 1));
+                        if constexpr (SPLIT == 1) {
+                            _Float16 hh, ll;
+                            sn_split(t, hh, ll);
+                            h[r] = hh; l[r] = ll;
+                        } else {
+                            h[r] = (_Float16)t;
+                            lo32[r] = (t - (float)h[r]) * 4096.f;
+                        }
+                    }
+                    const int ch = n * 16 + kq * 4;
+                    if (writer && ch < a.out_cp) {
+                        _Float16 *o = a.pool_out + (size_t)b * VOLo * a.pool_cs + ((size_t)(ch >> 3) * VOLo + vlin) * 8 + (ch & 7);
+                        *reinterpret_cast<half4 *>(o) = h;
+                        if constexpr (SPLIT == 1) *reinterpret_cast<half4 *>(o + a.pool_lo_off) = l;
+                        if constexpr (SPLIT == 2) {
+                            char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.pool_lo_off);
                             *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
                             *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
                         }

@@ -89,6 +89,7 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, co
         if (row_exp[o] != 0)
             for (size_t i = (size_t)o * L.cin * ntap; i < (size_t)(o + 1) * L.cin * ntap; ++i) Wn[i] = std::ldexp(Wn[i], row_exp[o]);
     }
+    if (ntap == 1) L.w_norm = Wn;
     const float *W = Wn.data();
     auto wat = [&](int o, int c8abs, int j, int tap) -> float {
         const int ci = c8abs * 8 + j;
@@ -186,6 +187,29 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, co
     return SN_OK;
 }
 
+// A fragments of a 16-output 1x1x1 layer for the EPI_SIDEPOOL epilogue of its producer (NF 16-channel fragments per lane group):
+// [K-chunk q][hi | lo][lane][8 halfs], lane (o = lane & 15, kq = lane >> 4), k = 8*kq + j <-> input channel 16*(2q + (j >= 4)) + 4*kq + (j & 3).
+static int pack_side_frag(sn_ctx *c, PackedConv &S, int producer_nf)
+{
+    if (S.cout != 16 || S.w_norm.size() != (size_t)16 * S.cin) return fail(SN_ERR_STATE, "%s: not a 16-output 1x1x1 layer", S.name.c_str());
+    const int nq = (producer_nf + 1) / 2;
+    std::vector<_Float16> h((size_t)nq * 2 * 64 * 8, (_Float16)0.f);
+    for (int q = 0; q < nq; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int o = lane & 15, kq = lane >> 4, ci = 16 * (2 * q + (j >> 2)) + 4 * kq + (j & 3);
+                const float w = ci < S.cin ? S.w_norm[(size_t)o * S.cin + ci] : 0.f;
+                const _Float16 hi = (_Float16)w;
+                h[((size_t)(q * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                h[((size_t)(q * 2 + 1) * 64 + lane) * 8 + j] = (_Float16)(w - (float)hi);
+            }
+    int rc;
+    if (S.side_frag) { dev_free_owned(c, S.side_frag); S.side_frag = nullptr; }
+    if ((rc = dev_alloc(c, &S.side_frag, h.size())) != SN_OK) return rc;
+    HIPCHK(hipMemcpy(S.side_frag, h.data(), h.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    return SN_OK;
+}
+
 struct TileChoice { int nf, nsplit, cs8max; };
 // Must agree with the kernel instantiations in run_net_t<SPLIT> (launch_conv verifies it).
 static TileChoice tile_for(const LayerSpec &sp, int split)
@@ -246,18 +270,33 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     auto &L = c->conv;
     RUN((launch_conv<CONV1>(c, L["conv1_1"], x0, 8, a1, 32, 0, 32, nullptr, S, s)));
     RUN((launch_conv<CONV1>(c, L["conv1_2"], a1, 32, b1, 32, 0, 32, nullptr, S, s)));
-    RUN((launch_conv<CONV1>(c, L["conv1_3"], b1, 32, a1, 32, 0, 32, nullptr, S, s)));
+    // conv1_3 with its two consumers in the epilogue: side_op1 (1x1x1 + BN + sigmoid -> concat channels 0..15) and pool1; the 32-channel
+    // full-resolution tensor itself is never written (nets/SurfaceNet.py:35-38).
     // f16x3 default (tail_m8 == 2): merge_conv_a AND merge_conv_b compute in f16m8 (main term f16, both correction terms on one MX-fp8
     // MFMA), so everything that writes the concat buffer stores it in the f16m8 format (OSPLIT = 2); upstream stays three-fp16-MFMA.
     const bool cat_m8 = SP == 1 && c->tail_m8 >= 2;
-    if (cat_m8) { if constexpr (SP == 1) RUN((launch_conv<1, 1, 4, 1, EPI_STORE, 1, 5, 2, 4, 0, 0, 2>(c, L["side_op1"], a1, 32, cat, 64, 0, 16, nullptr, S, s))); }
-    else RUN((launch_conv<SIDE>(c, L["side_op1"], a1, 32, cat, 64, 0, 16, nullptr, S, s)));
-    RUN((launch_pool<SP>(c, "pool1", a1, p1, S, s, 32)));
+    static const bool unfused = getenv("SN_NO_EPI_FUSION") != nullptr;      // A/B measurements: the three separate launches
+    if (!unfused) {
+        const SideFuse sf1{&L["side_op1"], cat, 64, 0, p1, 32};
+        if (cat_m8) { if constexpr (SP == 1) RUN((launch_conv<3, 1, 4, 2, EPI_SIDEPOOL, 1, 1, 7, 8, 0, 0, 2>(c, L["conv1_3"], b1, 32, none, 0, 0, 32, nullptr, S, s, 0, &sf1))); }
+        else RUN((launch_conv<3, 1, 4, 2, EPI_SIDEPOOL, SP, 1, (SP == 2 ? 2 : 7), 8, 0>(c, L["conv1_3"], b1, 32, none, 0, 0, 32, nullptr, S, s, 0, &sf1)));
+    } else {
+        RUN((launch_conv<CONV1>(c, L["conv1_3"], b1, 32, a1, 32, 0, 32, nullptr, S, s)));
+        if (cat_m8) { if constexpr (SP == 1) RUN((launch_conv<1, 1, 4, 1, EPI_STORE, 1, 5, 2, 4, 0, 0, 2>(c, L["side_op1"], a1, 32, cat, 64, 0, 16, nullptr, S, s))); }
+        else RUN((launch_conv<SIDE>(c, L["side_op1"], a1, 32, cat, 64, 0, 16, nullptr, S, s)));
+        RUN((launch_pool<SP>(c, "pool1", a1, p1, S, s, 32)));
+    }
     RUN((launch_conv<CONV2>(c, L["conv2_1"], p1, 32, a2, 80, 0, 80, nullptr, S, D2)));
     RUN((launch_conv<CONV2>(c, L["conv2_2"], a2, 80, b2, 80, 0, 80, nullptr, S, D2)));
-    RUN((launch_conv<CONV2>(c, L["conv2_3"], b2, 80, a2, 80, 0, 80, nullptr, S, D2)));
-    RUN((launch_conv<SIDE>(c, L["side_op2"], a2, 80, s2, 16, 0, 16, nullptr, S, D2)));
-    RUN((launch_pool<SP>(c, "pool2", a2, p2, S, D2, 80)));
+    if (!unfused) {
+        // conv2_3 likewise: side_op2 (-> the 16-channel half-resolution side map) and pool2 in its epilogue (nets/SurfaceNet.py:44-47)
+        const SideFuse sf2{&L["side_op2"], s2, 16, 0, p2, 80};
+        RUN((launch_conv<3, 1, 4, 5, EPI_SIDEPOOL, SP, (SP == 2 ? 1 : 2), (SP == 2 ? 2 : 1), 8, 0>(c, L["conv2_3"], b2, 80, none, 0, 0, 80, nullptr, S, D2, 0, &sf2)));
+    } else {
+        RUN((launch_conv<CONV2>(c, L["conv2_3"], b2, 80, a2, 80, 0, 80, nullptr, S, D2)));
+        RUN((launch_conv<SIDE>(c, L["side_op2"], a2, 80, s2, 16, 0, 16, nullptr, S, D2)));
+        RUN((launch_pool<SP>(c, "pool2", a2, p2, S, D2, 80)));
+    }
     RUN((launch_conv<CONV3>(c, L["conv3_1"], p2, 80, a3, 160, 0, 160, nullptr, S, D3)));
     RUN((launch_conv<CONV3>(c, L["conv3_2"], a3, 160, b3, 160, 0, 160, nullptr, S, D3)));
     RUN((launch_conv<CONV3>(c, L["conv3_3"], b3, 160, a3, 160, 0, 160, nullptr, S, D3)));
@@ -470,7 +509,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
     }
     { int rcw = ensure_workspace(c); if (rcw != SN_OK) return rcw; }
     // free previously loaded weights
-    for (auto &kv : c->conv) { dev_free_owned(c, kv.second.wpack); dev_free_owned(c, kv.second.scale); dev_free_owned(c, kv.second.shift); }
+    for (auto &kv : c->conv) { dev_free_owned(c, kv.second.wpack); dev_free_owned(c, kv.second.scale); dev_free_owned(c, kv.second.shift); dev_free_owned(c, kv.second.side_frag); }
     c->conv.clear();
     c->have_weights = false;
 
@@ -550,6 +589,9 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
         if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit, in_exp, oe.data())) != SN_OK) return rc;
         c->conv[L.name] = L;
     }
+    // side_op1 / side_op2 run inside the epilogues of conv1_3 / conv2_3 (EPI_SIDEPOOL): their A fragments in the producers' register order
+    if ((rc = pack_side_frag(c, c->conv["side_op1"], c->conv["conv1_3"].nf)) != SN_OK) return rc;
+    if ((rc = pack_side_frag(c, c->conv["side_op2"], c->conv["conv2_3"].nf)) != SN_OK) return rc;
     c->have_relw = false;
     if (n_params == kAllParams) {
         const sn_param_desc *d = descs + pi;

@@ -59,7 +59,12 @@ struct PackedConv {
     _Float16 *wpack = nullptr;     // device
     float *scale = nullptr, *shift = nullptr;  // device, nsplit*nf*16
     double macs_per_voxel = 0;
+    // 1x1x1 layers only: the normalised weights (cout x cin, after pack_conv's power-of-two scalings) and, when the layer is fused into
+    // its producer's epilogue (EPI_SIDEPOOL), its A fragments in the producer's register order (device)
+    std::vector<float> w_norm;
+    _Float16 *side_frag = nullptr;
 };
+
 
 struct ProfRec { int tag; hipEvent_t e0, e1; double flops, bytes; };
 struct ProfStat { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
@@ -203,9 +208,12 @@ static bool shape_is(const sn_param_desc &d, std::initializer_list<int> s)
 // A channels-last fp16 activation tensor: hi plane at p, lo plane (f16x3 mode) at p + lo elements.
 struct Act { _Float16 *p; long long lo; };
 
+// What EPI_SIDEPOOL needs beside the conv's own arguments: the fused 1x1x1 layer and the two destinations.
+struct SideFuse { const PackedConv *side; Act side_out; int side_cs, side_coff; Act pool_out; int pool_cs; };
+
 template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH, int NW, int PADV, int K2D = 0, int OSPLIT = -1>
 static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act out, int out_cs, int out_coff, int out_cp,
-                       float *out_f32, int B, int D, int DX = 0)
+                       float *out_f32, int B, int D, int DX = 0, const SideFuse *sf = nullptr)
 {
     using C = ConvCfg<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV, K2D>;
     if (DX <= 0) DX = D;
@@ -232,6 +240,13 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
             return fail(SN_ERR_ARG, "%s: a %d-group channel slab of a %dx%dx%d volume exceeds the 32 MiB this kernel's halo addressing covers", L.name.c_str(), C::CS8MAX, DX, D, D);
     }
     a.act = L.act;
+    if (EPI == EPI_SIDEPOOL) {
+        if (!sf || !sf->side || !sf->side->side_frag || sf->side->cin != L.cout || sf->side->cout != 16 || L.nsplit != 1 || L.act != 0 || (D & 1))
+            return fail(SN_ERR_STATE, "%s: fused side-conv / pool epilogue misconfigured", L.name.c_str());
+        a.side_w = sf->side->side_frag; a.side_scale = sf->side->scale; a.side_shift = sf->side->shift; a.side_act = sf->side->act;
+        a.side_out = sf->side_out.p; a.side_lo_off = sf->side_out.lo; a.side_cs = sf->side_cs; a.side_coff = sf->side_coff;
+        a.pool_out = sf->pool_out.p; a.pool_lo_off = sf->pool_out.lo; a.pool_cs = sf->pool_cs;
+    }
     if (c->d_num) {
         // one status bit per layer name (2-D similarityNet layers share bit 31)
         auto it = std::find(c->num_names.begin(), c->num_names.end(), L.name);
@@ -243,7 +258,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     a.nslab = (int)L.slab_c8.size();
     for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
     const double vox = (double)B * DX * D * D;
-    const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : L.cout));
+    const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : (EPI == EPI_SIDEPOOL ? 16 + L.cout / 8.0 : L.cout)));
     ProfScope ps(c, L.name, 2.0 * L.macs_per_voxel * vox, bytes);
     // persistent workgroups: one resident set, each walking tiles blockIdx.x, +gridDim.x, ...
     const int resident = std::max(1, c->num_cus * C::WG_PER_CU / L.nsplit);
