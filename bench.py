@@ -175,7 +175,7 @@ def post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, steps, keep_frac=0.1):
     return out
 
 
-def simil_net(surfacenet_amd, ctx, scene, steps, n=2048):
+def simil_net(surfacenet_amd, ctx, scene, steps, n=2040):        # = one internal chunk of the library (sn_simil.hip kSimChunk)
     """Extra, non-headline measurement: earlyRejection.patch2embedding's inner loop for one view --
     crop n 64x64 patches around projected cube centres, preprocess, similarityNet embedding -- without leaving HBM
     (sn_crop_embed); embeddings (n,128) copied to the host every step."""

@@ -296,16 +296,22 @@ conv3d_f16_mfma(ConvArgs a)
         }
         return issued;
     };
-    // ---- buffer-addressed halo staging (3-D nets) ------------------------------------------------------------------
+    // ---- buffer-addressed halo staging ----------------------------------------------------------------------------
     // The generic stage_halo above spends ~35 VALU + ~30 SALU instructions and an EXEC-masked branch per 1 KiB DMA on turning
     // (segment, lane) into a clamped global address. Here every lane keeps, per DMA slot k of its wave, ONE precomputed word:
-    // the byte offset of its halo voxel relative to the tile's halo origin inside the channel slab, plus validity bits for the six
+    // the byte offset of its halo voxel relative to the tile's halo origin inside the channel slab, plus validity bits for the
     // volume faces (and "never valid" for the tail of the last segment). Per DMA: (word & keep-mask of the tile) + tile offset ->
-    // voffset of a buffer_load..lds whose descriptor covers exactly the slab's c8n group planes of the sample; a voxel outside
-    // the volume keeps a high bit, fails the range check, and the hardware writes zeros ('same' padding / PadLayer).
-    // Precondition (checked by launch_conv): only the first / last tile along an axis has out-of-volume halo voxels, and
-    // CS8MAX * VOL * 16 + halo slack < 2^25 bytes.
-    constexpr bool BUFH = (K2D == 0);
+    // voffset of a buffer_load..lds whose descriptor covers exactly the slab's c8n group planes; a voxel outside the volume keeps a
+    // high bit, fails the range check, and the hardware writes zeros ('same' padding / PadLayer).
+    //   3-D nets: six face bits + "never" in bits 25..31, offsets < 2^25 relative to the sample's slab.
+    //   2-D nets (K2D; x = image index, no halo along x): four face bits (y, z) in bits 28..31, "never" = offset 0x0FFFFFF0; the
+    //   descriptor starts at the TILE's first image, so offsets (up to one group plane of the whole chunk) stay < 2^28. Images past
+    //   the end of a partial last tile read whatever follows inside the descriptor (or zeros): their outputs are never stored.
+    // Preconditions (checked by launch_conv): only the first / last tile along an axis has out-of-volume halo voxels, and the
+    // slab fits the offset field. The one-plane f16 mode of the 2-D nets (4-group slabs: up to 400 MB) keeps the generic path.
+    constexpr bool BUFH = (K2D == 0) || (SPLIT != 0);
+    constexpr unsigned FB_YLO = K2D ? (1u << 31) : HB_YLO, FB_YHI = K2D ? (1u << 30) : HB_YHI, FB_ZLO = K2D ? (1u << 29) : HB_ZLO,
+                       FB_ZHI = K2D ? (1u << 28) : HB_ZHI, FB_NEVER = K2D ? 0x0FFFFFF0u : HB_ALWAYS, FB_OFFMASK = K2D ? 0x0FFFFFFFu : HB_OFFMASK;
     unsigned hword[HT];
     if constexpr (BUFH) {
         const int xl = (a.tiles_x - 1) * C::TX, yl = (a.tiles_y - 1) * C::TY, zl = (a.tiles_z - 1) * C::TZ;
@@ -317,36 +323,48 @@ conv3d_f16_mfma(ConvArgs a)
             const int hv = slot / C::SLOTS, part = slot - hv * C::SLOTS;
             const int hz = hv % C::HZ, hy = (hv / C::HZ) % C::HY, hx = hv / (C::HZ * C::HY);
             unsigned o = ((unsigned)part * (unsigned)VOL + (unsigned)((hx * D + hy) * D + hz)) * 16u;
-            if (hv >= C::HVOX || li >= C::NSEG * NPL) o = HB_ALWAYS;
-            if (hx < C::RX) o |= HB_XLO;
-            if (xl - C::RX + hx >= DX) o |= HB_XHI;
-            if (hy < C::R) o |= HB_YLO;
-            if (yl - C::R + hy >= D) o |= HB_YHI;
-            if (hz < C::R) o |= HB_ZLO;
-            if (zl - C::R + hz >= D) o |= HB_ZHI;
+            if (hv >= C::HVOX || li >= C::NSEG * NPL) o = FB_NEVER;
+            else {
+                if constexpr (K2D == 0) {
+                    if (hx < C::RX) o |= HB_XLO;
+                    if (xl - C::RX + hx >= DX) o |= HB_XHI;
+                }
+                if (hy < C::R) o |= FB_YLO;
+                if (yl - C::R + hy >= D) o |= FB_YHI;
+                if (hz < C::R) o |= FB_ZLO;
+                if (zl - C::R + hz >= D) o |= FB_ZHI;
+            }
             hword[k] = o;
         });
     }
     // tile-dependent scalars of the buffer path: keep-mask and byte offset of the halo origin (may be negative)
     auto tile_halo_consts = [&](int x0, int y0, int z0, unsigned &keep, int &toff) {
-        unsigned inv = HB_ALWAYS;
-        if (x0 == 0) inv |= HB_XLO;
-        if (x0 == (a.tiles_x - 1) * C::TX) inv |= HB_XHI;
-        if (y0 == 0) inv |= HB_YLO;
-        if (y0 == (a.tiles_y - 1) * C::TY) inv |= HB_YHI;
-        if (z0 == 0) inv |= HB_ZLO;
-        if (z0 == (a.tiles_z - 1) * C::TZ) inv |= HB_ZHI;
-        keep = HB_OFFMASK | inv;
-        toff = (((x0 - C::RX) * D + (y0 - C::R)) * D + (z0 - C::R)) * 16;
+        unsigned inv = K2D ? 0u : HB_ALWAYS;
+        if constexpr (K2D == 0) {
+            if (x0 == 0) inv |= HB_XLO;
+            if (x0 == (a.tiles_x - 1) * C::TX) inv |= HB_XHI;
+        }
+        if (y0 == 0) inv |= FB_YLO;
+        if (y0 == (a.tiles_y - 1) * C::TY) inv |= FB_YHI;
+        if (z0 == 0) inv |= FB_ZLO;
+        if (z0 == (a.tiles_z - 1) * C::TZ) inv |= FB_ZHI;
+        keep = FB_OFFMASK | inv;
+        toff = K2D ? ((y0 - C::R) * D + (z0 - C::R)) * 16 : (((x0 - C::RX) * D + (y0 - C::R)) * D + (z0 - C::R)) * 16;
     };
-    // issues this wave's halo DMAs [k0, k0+kn) of (sample b, channel groups [c0, c0+c8n)) into halo buffer xb
-    // issues ALL of this wave's halo DMAs of (sample b, channel groups [c0, c0+c8n)) into halo buffer xb; returns how many
+    // issues ALL of this wave's halo DMAs of (sample b [2-D: first image x0 of the tile], channel groups [c0, c0+c8n)) into halo buffer xb
     auto stage_halo_buf = [&](int b, unsigned keep, int toff, int c0, int c8n, int xb) -> int {
         // opaque to the optimiser: otherwise it hoists (hword[k] & keep) + toff and the descriptors of BOTH candidate tiles out of the
         // K loop as loop invariants (8 VGPRs + 16 SGPRs live across it) and the accumulators spill
         asm volatile("" : "+s"(b), "+s"(keep), "+s"(toff), "+s"(c0));
-        const char *base0 = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)b * VOL * a.in_cs + (size_t)c0 * VOL * 8);
-        const int nrec = c8n * (int)VOL * 16;
+        const char *base0;
+        int nrec;
+        if constexpr (K2D == 0) {
+            base0 = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)b * VOL * a.in_cs + (size_t)c0 * VOL * 8);
+            nrec = c8n * (int)VOL * 16;
+        } else {      // b = x0: the descriptor begins at the tile's first image inside group plane c0 and ends with group plane c0+c8n-1
+            base0 = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)c0 * VOL * 8 + (size_t)b * D * D * 8);
+            nrec = (c8n * (int)VOL - b * D * D) * 16;
+        }
         int issued = 0;
         static_for<0, HT>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -431,7 +449,7 @@ conv3d_f16_mfma(ConvArgs a)
             unsigned keep;
             tile_origin(tile, b, x0, y0, z0);
             tile_halo_consts(x0, y0, z0, keep, toff);
-            stage_halo_buf(b, keep, toff, 0, c8n, 0);
+            stage_halo_buf(K2D ? x0 : b, keep, toff, 0, c8n, 0);
         } else stage_halo(tile, 0, c8n, 0, 0, HT);
         write_koff(c8n, 0);
         const int nch = wchunks_of(c8n);
@@ -461,6 +479,7 @@ conv3d_f16_mfma(ConvArgs a)
                 int nx0, ny0, nz0;
                 tile_origin(tile + tstride, nxt_b, nx0, ny0, nz0);
                 tile_halo_consts(nx0, ny0, nz0, nxt_keep, nxt_toff);
+                if constexpr (K2D != 0) nxt_b = nx0;                  // 2-D nets: the descriptor is tile-relative along x
             }
         }
 
@@ -547,7 +566,7 @@ conv3d_f16_mfma(ConvArgs a)
                 int hnow = 0;
                 if constexpr (BUFH) {
                     if (have_next && !(SN_ABL & 1) && p == 0)
-                        hnow = stage_halo_buf(last_slab ? nxt_b : b, last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                        hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
                 } else if (have_next && !(SN_ABL & 1) && hdone < HT && (p + 1 < npiece || npiece == 1)) {
                     const int left = HT - hdone;
                     const int kn = (p + 2 >= npiece || left < HQ) ? left : HQ;

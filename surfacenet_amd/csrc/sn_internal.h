@@ -230,14 +230,16 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     a.D = D; a.DX = DX;
     a.tiles_x = (DX + C::TX - 1) / C::TX; a.tiles_y = (D + C::TY - 1) / C::TY; a.tiles_z = (D + C::TZ - 1) / C::TZ;
     a.total_tiles = B * a.tiles_x * a.tiles_y * a.tiles_z;
-    if (K2D == 0) {
+    {
         // preconditions of the buffer-addressed halo staging (conv3d_mfma.h, stage_halo_buf)
         auto edge_only = [](int n, int T, int R) { return n <= T || n % T == 0 || n % T >= R; };   // only the first / last tile sees padding
-        if (!edge_only(DX, C::TX, C::RX) || !edge_only(D, C::TY, C::R) || !edge_only(D, C::TZ, C::R))
+        if ((K2D == 0 && !edge_only(DX, C::TX, C::RX)) || !edge_only(D, C::TY, C::R) || !edge_only(D, C::TZ, C::R))
             return fail(SN_ERR_ARG, "%s: volume extent %d is not supported by this kernel's halo addressing (extent mod 8 must be 0 or >= %d)", L.name.c_str(), D, C::R);
-        const long long slab_bytes = (long long)C::CS8MAX * DX * D * D * 16;
-        if (slab_bytes + 4LL * C::HVOX * 16 >= (1LL << 25))
+        const long long plane = (long long)DX * D * D * 16, slack = 4LL * C::HVOX * 16;
+        if (K2D == 0 && C::CS8MAX * plane + slack >= (1LL << 25))
             return fail(SN_ERR_ARG, "%s: a %d-group channel slab of a %dx%dx%d volume exceeds the 32 MiB this kernel's halo addressing covers", L.name.c_str(), C::CS8MAX, DX, D, D);
+        if (K2D != 0 && SPLIT != 0 && C::CS8MAX * plane + slack >= 0x0FFFFFF0LL - (1 << 16))
+            return fail(SN_ERR_ARG, "%s: %d images of %dx%d exceed the 256 MiB this kernel's halo addressing covers per channel slab", L.name.c_str(), DX, D, D);
     }
     a.act = L.act;
     if (EPI == EPI_SIDEPOOL) {

@@ -9,7 +9,10 @@ static const int kSimC[14] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512,
 static const int kSimStage[13] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4};                          // H = 64 >> stage
 static const char *const kSimName[13] = {"s_conv1_1", "s_conv1_2", "s_conv2_1", "s_conv2_2", "s_conv3_1", "s_conv3_2", "s_conv3_3",
                                          "s_conv4_1", "s_conv4_2", "s_conv4_3", "s_conv5_1", "s_conv5_2", "s_conv5_3"};
-static constexpr int kSimParams = 30, kSimChunk = 2048, kSimNF = 4;
+static constexpr int kSimParams = 30, kSimNF = 4;
+// patches per pass: two 64x64 group planes of a chunk (2040 * 4096 * 16 B * 2 = 267.4 MB) must stay below the 2^28 - 16 offset field of the
+// conv kernel's buffer-addressed halo staging (conv3d_mfma.h)
+static constexpr int kSimChunk = 2040;
 // channel groups per slab / K-chunks per weight piece: f16x3 (two activation planes) 2 / 2 (3 measured equal); f16 (one plane)
 // 4 / 3, i.e. 36 groups = exactly 9 chunks per slab: +18 % in that mode
 #define SIMCS8 (SP == 0 ? 4 : 2)
