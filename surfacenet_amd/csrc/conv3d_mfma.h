@@ -59,6 +59,9 @@
 #ifndef SN_STATIC_PRIO
 #define SN_STATIC_PRIO 1   // +0.7 % on the 3-D f16x3 / f16m8 kernels (merge_conv_b -1.6 %); -0.8 % in f16 mode and on the 2-D kernels -> off there
 #endif
+#ifndef SN_MX_B128
+#define SN_MX_B128 1     // f16m8 MX step: a lane covers BOTH correction terms of 2 channel groups (two 16-byte slot reads) instead of ONE term of 4 groups
+#endif                   // (four 8-byte reads): half the activation-fetch instructions of the step, 2 tap offsets instead of 4; the weight packing follows (pack_conv)
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
 #endif
@@ -537,11 +540,16 @@ conv3d_f16_mfma(ConvArgs a)
             };
             v4i k4, k4n;                                                      // f16m8: tap offsets of the MX step's 4 groups
             const unsigned k4_a = koff_a - kq * 4 + (unsigned)(4 * (kq & 1)) * 4;
+            long long k2, k2n;                                                // SN_MX_B128: tap offsets of this lane's 2 groups (8p + 2kq, +1)
+            const unsigned k2_a = koff_a + kq * 4;
             {
                 int k0;
                 lds_read32<0>(k0, koff_a);
                 lds_read32<16>(ko1, koff_a);
-                if constexpr (SPLIT == 2) lds_read128i<0>(k4, k4_a);
+                if constexpr (SPLIT == 2) {
+                    if constexpr (SN_MX_B128) lds_read64<0>(k2, k2_a);
+                    else lds_read128i<0>(k4, k4_a);
+                }
                 lgkm_wait<0>();
                 issue_x(xc, k0);
                 lgkm_wait<0>();
@@ -553,6 +561,7 @@ conv3d_f16_mfma(ConvArgs a)
                 // f16m8: fp8 operands of this piece's MX step; fetched in the middle of the piece (see chunk 1, n == 0)
                 v8i x8[SPLIT == 2 ? MF : 1];
                 long long x8q[SPLIT == 2 ? MF : 1][4];
+                v4i x8h[SPLIT == 2 ? MF : 1][2];
                 lds_read128<0>(wr[0][0], wp);
                 if constexpr (SPLIT == 1) lds_read128<1024>(wr[0][1], wp);
                 // next weight piece: the following piece of this slab, else the first piece of what comes next
@@ -587,7 +596,7 @@ conv3d_f16_mfma(ConvArgs a)
                                 lds_read128<wo>(wr[nxt][0], wp);
                                 if constexpr (SPLIT == 1) lds_read128<wo + 1024>(wr[nxt][1], wp);
                             }
-                            lgkm_wait<((more_n || more_c) ? NPLM : 0) + (n == 1 ? 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? 4 * MF + 1 : 0) : 0)>();
+                            lgkm_wait<((more_n || more_c) ? NPLM : 0) + (n == 1 ? 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? (SN_MX_B128 ? 2 : 4) * MF + 1 : 0) : 0)>();
                             if constexpr (!(SN_ABL & 4)) {
                                 if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(1);
                                 if constexpr (SPLIT == 1) {
@@ -613,13 +622,20 @@ conv3d_f16_mfma(ConvArgs a)
                                     // piece ahead); also fetch the next piece's tap offsets
                                     static_for<0, MF>([&](auto mc) {
                                         constexpr int m = decltype(mc)::value;
-                                        const unsigned ad = xaddr[m] + C::XPLANE + (kq >> 1) * 8;   // lanes 0-31: fp8(hi), 32-63: fp8(lo*2^12)
-                                        lds_read64<0>(x8q[m][0], ad + (unsigned)k4[0]);
-                                        lds_read64<0>(x8q[m][1], ad + (unsigned)k4[1]);
-                                        lds_read64<0>(x8q[m][2], ad + (unsigned)k4[2]);
-                                        lds_read64<0>(x8q[m][3], ad + (unsigned)k4[3]);
+                                        if constexpr (SN_MX_B128) {
+                                            const unsigned ad = xaddr[m] + C::XPLANE;               // whole 16-byte slots [fp8(hi) x8 | fp8(lo*2^12) x8]
+                                            lds_read128i<0>(x8h[m][0], ad + (unsigned)(int)k2);
+                                            lds_read128i<0>(x8h[m][1], ad + (unsigned)(int)(k2 >> 32));
+                                        } else {
+                                            const unsigned ad = xaddr[m] + C::XPLANE + (kq >> 1) * 8;   // lanes 0-31: fp8(hi), 32-63: fp8(lo*2^12)
+                                            lds_read64<0>(x8q[m][0], ad + (unsigned)k4[0]);
+                                            lds_read64<0>(x8q[m][1], ad + (unsigned)k4[1]);
+                                            lds_read64<0>(x8q[m][2], ad + (unsigned)k4[2]);
+                                            lds_read64<0>(x8q[m][3], ad + (unsigned)k4[3]);
+                                        }
                                     });
-                                    lds_read128i<0>(k4n, k4_a + (unsigned)(8 * (p + 1)) * 4);
+                                    if constexpr (SN_MX_B128) lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
+                                    else lds_read128i<0>(k4n, k4_a + (unsigned)(8 * (p + 1)) * 4);
                                 }
                             }
                         });
@@ -638,10 +654,14 @@ conv3d_f16_mfma(ConvArgs a)
                         constexpr int mxo = 2 * NF * 1024;
     #pragma unroll
                         for (int m = 0; m < MF; ++m) {
-                            x8[m][0] = (int)x8q[m][0]; x8[m][1] = (int)(x8q[m][0] >> 32); x8[m][2] = (int)x8q[m][1]; x8[m][3] = (int)(x8q[m][1] >> 32);
-                            x8[m][4] = (int)x8q[m][2]; x8[m][5] = (int)(x8q[m][2] >> 32); x8[m][6] = (int)x8q[m][3]; x8[m][7] = (int)(x8q[m][3] >> 32);
+                            if constexpr (SN_MX_B128) {
+                                x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                            } else {
+                                x8[m][0] = (int)x8q[m][0]; x8[m][1] = (int)(x8q[m][0] >> 32); x8[m][2] = (int)x8q[m][1]; x8[m][3] = (int)(x8q[m][1] >> 32);
+                                x8[m][4] = (int)x8q[m][2]; x8[m][5] = (int)(x8q[m][2] >> 32); x8[m][6] = (int)x8q[m][3]; x8[m][7] = (int)(x8q[m][3] >> 32);
+                            }
                         }
-                        k4 = k4n;
+                        if constexpr (SN_MX_B128) k2 = k2n; else k4 = k4n;
                         v4i w8[2][2];
                         lds_read128i<mxo>(w8[0][0], wp);
                         lds_read128i<mxo + 1024>(w8[0][1], wp);

@@ -52,8 +52,8 @@ static unsigned char fp8_e4m3(float v)
 //   split 0 (f16)  : [slab][chunk][nf]{ hi fragment: 64 lanes x 8 halfs }
 //   split 1 (f16x3): [slab][chunk][nf]{ hi fragment, lo fragment }
 //   split 2 (f16m8): [slab][piece of 8 groups]{ chunk 2p: nf hi fragments | chunk 2p+1: nf hi fragments |
-//                     nf MX fragments (2 KiB: k bytes 0-15 of all 64 lanes, then 16-31); lane (row = l&15, q = l>>4): q<2 -> fp8(w_lo * 2^12) of
-//                     groups 8p+4q..+3, q>=2 -> fp8(w_hi) of groups 8p+4(q-2)..+3 }   (every piece is full-size, zero padded)
+//                     nf MX fragments (2 KiB: k bytes 0-15 of all 64 lanes, then 16-31); lane (row = l&15, q = l>>4): groups 8p+2q, 8p+2q+1,
+//                     four 8-byte sections [fp8(w_lo*2^12) g0 | fp8(w_hi) g0 | fp8(w_lo*2^12) g1 | fp8(w_hi) g1] }   (every piece full-size, zero padded)
 // Dynamic-range normalisation (exact: every factor is a power of two). The split-fp16 storage of weights and activations has
 // fp16's exponent range, so before packing
 //   * input channel c of the layer arrives pre-multiplied by 2^in_exp[c] (its producer's out_exp): W[o][c] *= 2^-in_exp[c];
@@ -151,13 +151,16 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, co
                             const int o = (ns * nf + f) * 16 + (lane & 15), q = lane >> 4;
                             unsigned char *frag = mx + (size_t)f * 2048;   // two lane-linear 1 KiB halves: k bytes 0-15 | 16-31
                             for (int i = 0; i < 4; ++i) {
-                                const int g = 8 * p + 4 * (q & 1) + i;
+                                // SN_MX_B128: lane quarter q covers groups 8p+2q, 8p+2q+1, 8-byte sections [w_lo | w_hi | w_lo | w_hi] (the
+                                // activation slots read [x_hi | x_lo]); else: q<2 -> w_lo, q>=2 -> w_hi of the 4 groups 8p + 4(q&1) + i
+                                const int g = SN_MX_B128 ? 8 * p + 2 * q + (i >> 1) : 8 * p + 4 * (q & 1) + i;
+                                const bool lo_part = SN_MX_B128 ? !(i & 1) : q < 2;
                                 if (g >= G) continue;
                                 for (int j = 0; j < 8; ++j) {
                                     const float w = wat(o, c8_0 + g % c8n, j, g / c8n);
                                     const float hi = (float)(_Float16)w;
                                     const int kb = i * 8 + j;
-                                    frag[(kb >> 4) * 1024 + lane * 16 + (kb & 15)] = q < 2 ? fp8_e4m3((w - hi) * 4096.f) : fp8_e4m3(hi);
+                                    frag[(kb >> 4) * 1024 + lane * 16 + (kb & 15)] = lo_part ? fp8_e4m3((w - hi) * 4096.f) : fp8_e4m3(hi);
                                 }
                             }
                         }
