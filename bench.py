@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--no-s64", action="store_true", help="skip the extra s=64 measurement")
     ap.add_argument("--no-simil", action="store_true", help="skip the extra similarityNet (early rejection) measurement")
     ap.add_argument("--no-post-pass", action="store_true", help="skip the extra whole-loop-body (ray pooling / dense2sparse) measurement")
+    ap.add_argument("--no-scenes", action="store_true", help="skip the extra end-to-end scene samples (BASELINE configs[2] and [4] on their dataset calibration)")
+    ap.add_argument("--scene-cubes", type=int, default=4000, help="cubes sampled evenly from each scene's grid for the scene samples (0 = the whole grid: 195,360 / 15,456)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -390,6 +392,17 @@ def main():
             out["loop_body_with_post_pass"] = post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, max(3, args.steps // 2))
         if world == 1 and not args.no_simil:
             out["similarity_net"] = simil_net(surfacenet_amd, ctx, scene, max(2, args.steps // 3))
+        if world == 1 and s == 32 and not args.no_scenes:
+            # Extra, non-headline: reconstruct_scene end to end (early rejection -> view-pair selection -> cube loop -> sparse lists) on the
+            # calibration and cube grid of DTU scan9 (49 views, N_vp = 5) and Middlebury dino (16 views, 16 view pairs); synthetic views and
+            # weights; a bounded even sample of each grid by default. Whole-grid runs: profiles/r2/scene_*.json (tools/bench_scene.py).
+            ctx.close()
+            ctx = None
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_scene
+            lim = ["--max-cubes", str(args.scene_cubes)] if args.scene_cubes else []
+            out["scene_dtu_scan9"] = bench_scene.run(["--config", "dtu_scan9"] + lim)
+            out["scene_dino"] = bench_scene.run(["--config", "dino"] + lim)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, values, s, n_vp)
         try:   # RCCL's banner sits in the C stdio buffer: push it out first so that the JSON line is the last line of stdout
@@ -400,7 +413,8 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

@@ -57,7 +57,8 @@ def build_scene(a):
     return P, imgs, cubes, cube_D_mm, Dc, n_vp
 
 
-def main():
+def run(argv):
+    """-> the result dict (bench.py embeds bounded samples of the two dataset configurations in its JSON line)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="synthetic", choices=["synthetic", "dtu_scan9", "dino"])
     ap.add_argument("--views", type=int, default=8)
@@ -66,7 +67,7 @@ def main():
     ap.add_argument("--n-vp", type=int, default=0)
     ap.add_argument("--max-cubes", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0, help="cubes per SurfaceNet batch (default: max_samples / n_vp; the reference's is 14 at s=32, params.py:117-118)")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     from surfacenet_amd import SurfaceNet, reconstruct, runtime, similarityNet, weights
 
     t0 = time.perf_counter()
@@ -93,9 +94,9 @@ def main():
            "valid_cubes_per_s_in_loop": round(n_valid / max(stages.get("cube_loop", 0.0), 1e-9), 1),
            "patches_per_s": round(int(res["inScope_cubes_vs_views"].sum()) / max(stages.get("patch2embedding", 0.0), 1e-9), 1),
            "data": "calibration + cube grid of the dataset; synthetic noise views and random-init networks"}
-    print(json.dumps(out))
     runtime.reset()
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(run(sys.argv[1:])))
