@@ -356,7 +356,8 @@ def main():
             "value": round(cubes_per_s, 2), "unit": "cubes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
-            "config": {"workload": "synthetic 2-view 1600x1200, s=%d, batch=%d cubes/GPU, N_viewpair=%d (BASELINE.json configs[1])" % (s, n, n_vp),
+            "config": {"workload": "synthetic 2-view 1600x1200, s=%d, batch=%d cubes/GPU, N_viewpair=%d (%s)" % (
+                s, n, n_vp, "BASELINE.json configs[1]" if (s, n, n_vp) == (32, 64, 2) else ("one GPU's shard of BASELINE.json configs[3]: s=64, 256 cubes over 8 GPUs" if (s, n) == (64, 32) else "non-default workload")),
                        "cubes_per_gpu": n, "samples_per_step": n * n_vp * world, "parallelism": "cube-sharded x%d%s" % (world, (", RCCL all-gather of fused probabilities" + (" (native sn_allgather_f32_dev)" if native else " (torch.distributed)")) if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": "conv3d_f16_mfma<%s>" % dom, "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
