@@ -321,3 +321,31 @@ def test_hot_loop_reference_batching_31_cubes_batch_14(sn):
             assert np.array_equal(pred, whole_f[pos:pos + k]) and np.array_equal(unf, whole_u[pos:pos + k])
             pos += k
     assert sizes == [14, 14, 3] and np.array_equal(seen, validCubes.astype(int))
+
+
+def test_repeated_full_batches_are_bit_identical(sn):
+    """Race screen for the LDS-DMA / counted-wait pipeline of the conv kernel (a ds_read that overtakes its DMA shows up as rare, load
+    dependent wrong tiles, never as a crash): 30 back-to-back passes over the full config-2 batch, device-resident, with a second
+    context hammering the same GPU from another stream in between, must reproduce the first pass's bits every time - every voxel."""
+    import synth
+    s, n, n_vp = 32, 64, 2
+    sc = golden_util.synthetic_scene(n, n_vp, s=s, seed=21)
+    values = list(synth.calibrated_params(0))
+    with sn.Context(cube_D=s, max_samples=n * n_vp) as ctx, sn.Context(cube_D=16, max_samples=16) as other:
+        for c in (ctx, other):
+            c.load_param_values(values); c.set_cameras(sc["cams"]); c.set_images(sc["imgs"])
+        d = [ctx.upload(sc[k]) for k in ("pairs", "xyz", "resol", "w")]
+        o = [other.upload(sc[k][:8]) for k in ("pairs", "xyz", "resol", "w")]
+        d_fused, d_unf = ctx.dev_alloc(n * s ** 3 * 4), ctx.dev_alloc(n * n_vp * s ** 3 * 4)
+        o_fused = other.dev_alloc(8 * 16 ** 3 * 4)
+        first_f = np.empty((n, s, s, s), np.float32); first_u = np.empty((n, n_vp, s, s, s), np.float32)
+        f = np.empty_like(first_f); u = np.empty_like(first_u)
+        for it in range(30):
+            if it % 3:
+                other.cvc_forward_dev(8, n_vp, o[0], o[1], o[2], o[3], o_fused)           # concurrent work on another stream
+            ctx.cvc_forward_dev(n, n_vp, d[0], d[1], d[2], d[3], d_fused, d_unf)
+            ctx.d2h(f if it else first_f, d_fused); ctx.d2h(u if it else first_u, d_unf)
+            if it:
+                assert np.array_equal(f, first_f) and np.array_equal(u, first_u), "pass %d differs from pass 0" % it
+        other.synchronize(); ctx.synchronize()
+        assert np.isfinite(first_u).all() and first_u.std() > 0.01
