@@ -62,6 +62,16 @@
 #ifndef SN_MX_B128
 #define SN_MX_B128 1     // f16m8 MX step: a lane covers BOTH correction terms of 2 channel groups (two 16-byte slot reads) instead of ONE term of 4 groups
 #endif                   // (four 8-byte reads): half the activation-fetch instructions of the step, 2 tap offsets instead of 4; the weight packing follows (pack_conv)
+// The two 8-voxel z-rows of a voxel fragment lie ROWGAP y-rows apart in the halo tile (1 = adjacent). Which LDS banks the four lane groups of
+// a ds_read_b128 X-fragment read hit depends on it; measured (PMC SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, r2v): gap 4 takes the 3x3x3
+// layers from 0.21-0.40 to 0.04-0.17 (conv2/3 0.31 -> 0.04, merge 0.23 -> 0.11, conv1 0.40 -> 0.17), +0.8 % end to end; it hurts the 1x1x1
+// side ops (0.28 -> 0.44), which keep gap 1.
+#ifndef SN_ROWGAP_3x3
+#define SN_ROWGAP_3x3 4
+#endif
+#ifndef SN_ROWGAP_DIL2
+#define SN_ROWGAP_DIL2 4
+#endif
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
 #endif
@@ -417,6 +427,8 @@ conv3d_f16_mfma(ConvArgs a)
     auto frag_xyz = [&](int m, int &hx, int &hy, int &hz) {
         if constexpr (C::F4) { hx = wave * MF + m; hy = v >> 2; hz = v & 3; }
         else if constexpr (PMAP) { hx = 2 * (wave & 3) + (m >> 1); hy = 4 * (wave >> 2) + 2 * (m & 1) + (v >> 3); hz = v & 7; }
+        else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 4) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
+        else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 2) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
         else { hx = wave * C::XS + (m >> 2); hy = 2 * (m & 3) + (v >> 3); hz = v & 7; }
     };
     int xbase[MF];
@@ -715,7 +727,9 @@ conv3d_f16_mfma(ConvArgs a)
             constexpr int YX = C::F4 ? 4 : 8;                       // lane distance of the row partner
 #pragma unroll
             for (int m = 0; m < MF; ++m) {
-                const int gx = x0 + (C::F4 ? wave * MF + m : wave * C::XS + (m >> 2)), gy = y0 + (C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3)), gz = z0 + (C::F4 ? (v & 3) : (v & 7));
+                int hx_, hy_, hz_;
+                frag_xyz(m, hx_, hy_, hz_);
+                const int gx = x0 + hx_, gy = y0 + hy_, gz = z0 + hz_;
                 const bool writer = !(v & 1) && !(v & YX) && gx < DX && gy < D && gz < D;     // D is even: the whole quad is inside
                 const size_t vlin = ((size_t)gx * Do + (gy >> 1)) * Do + (gz >> 1);
 #pragma unroll
@@ -913,7 +927,9 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int m = mp + e;
-                    const int gx = x0 + (C::F4 ? wave * MF + m : wave * C::XS + (m >> 2)), gy = y0 + (C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3)), gz = z0 + (C::F4 ? (v & 3) : (v & 7));
+                    int hx_, hy_, hz_;
+                frag_xyz(m, hx_, hy_, hz_);
+                const int gx = x0 + hx_, gy = y0 + hy_, gz = z0 + hz_;
                     valid[e] = gx < DX && gy < D && gz < D;
                     vlin[e] = ((size_t)gx * D + gy) * D + gz;
                 }
@@ -989,7 +1005,9 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
                 }
-                const int gx = x0 + (C::F4 ? wave * MF + m : wave * C::XS + (m >> 2)), gy = y0 + (C::F4 ? (v >> 2) : 2 * (m & 3) + (v >> 3)), gz = z0 + (C::F4 ? (v & 3) : (v & 7));
+                int hx_, hy_, hz_;
+                frag_xyz(m, hx_, hy_, hz_);
+                const int gx = x0 + hx_, gy = y0 + hy_, gz = z0 + hz_;
                 const bool valid = gx < DX && gy < D && gz < D;
                 const size_t vox = ((size_t)(b * DX + gx) * D + gy) * D + gz;
                 p += __shfl_xor(p, 16);
