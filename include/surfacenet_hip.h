@@ -47,8 +47,8 @@ typedef struct {
 } sn_param_desc;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
-/* cube_D = s of the s^3 colored voxel cube (params.py:65, 32 or 64; any multiple of 4 >= 8 is
- * accepted for tests); max_samples = largest n*n_vp processed per internal pass (activation
+/* cube_D = s of the s^3 colored voxel cube (params.py:65, 32 or 64; any multiple of 4 in [8,96]
+ * except 36 and 68 is accepted); max_samples = largest n*n_vp processed per internal pass (activation
  * workspace is sized for it; larger calls are chunked). Returns NULL on failure (sn_last_error). */
 sn_ctx *sn_create(int device_id, int cube_D, int max_samples);
 void sn_destroy(sn_ctx *ctx);

@@ -425,7 +425,13 @@ static int ensure_workspace(sn_ctx *c)
 
 sn_ctx *sn_create(int device_id, int cube_D, int max_samples)
 {
-    if (cube_D < 8 || cube_D % 4 != 0 || cube_D > 128) { fail(SN_ERR_ARG, "cube_D must be a multiple of 4 in [8,128], got %d", cube_D); return nullptr; }
+    if (cube_D < 8 || cube_D % 4 != 0 || cube_D > 96) { fail(SN_ERR_ARG, "cube_D must be a multiple of 4 in [8,96], got %d (the reference uses 32 and 64, params.py:65)", cube_D); return nullptr; }
+    {
+        // the conv kernel's halo addressing needs, per layer extent n (cube_D, /2, /4) and halo radius R: n <= 8, n % 8 == 0 or n % 8 >= R
+        // (launch_conv checks it per launch; refuse here what would fail there: the dilated layers, R = 2, at extent cube_D/4)
+        const int n4 = cube_D / 4;
+        if (n4 > 8 && n4 % 8 == 1) { fail(SN_ERR_ARG, "cube_D = %d is not supported (cube_D/4 = %d leaves a 1-voxel partial tile under the dilation-2 layers)", cube_D, n4); return nullptr; }
+    }
     if (max_samples < 1) { fail(SN_ERR_ARG, "max_samples must be >= 1"); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fail(SN_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback"); return nullptr; }
