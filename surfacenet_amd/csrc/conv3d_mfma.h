@@ -72,6 +72,16 @@
 #ifndef SN_ROWGAP_DIL2
 #define SN_ROWGAP_DIL2 4
 #endif
+#ifndef SN_WDIST
+#define SN_WDIST 2        // weight fragments are fetched from LDS this many MFMA groups ahead of their use (1 or 2). A wave that holds the SIMD's
+#endif                    // priority issues a group of 4 MFMAs in ~68 clocks, far less than a loaded ds_read_b128 takes: at distance 1 it stalls on
+                          // every group (wave_timing.py: the prioritised wave needs 3,900 clocks per piece for 1,930 clocks of MFMA issue)
+#ifndef SN_DMA_LATE
+#define SN_DMA_LATE 0     // issue the piece's DMAs behind its first MFMA group instead of in front of it: measured null (r2x: +-0.3 %, 30-step A/B)
+#endif
+#ifndef SN_TIMING
+#define SN_TIMING 0       // diagnostic build: per-wave shader-clock totals (whole kernel, vmcnt wait, barrier wait) added into a.status[1..] (results stay valid)
+#endif
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
 #endif
@@ -479,6 +489,8 @@ conv3d_f16_mfma(ConvArgs a)
 #endif
     int xb = 0;     // halo / tap-table buffer holding the current slab
     int wbi = 0;    // weight buffer holding the current piece
+    long long t_vm = 0, t_bar = 0, n_piece = 0;
+    const long long t_kernel0 = SN_TIMING ? __builtin_readcyclecounter() : 0;
     bool bad = false;   // a stored value left the fp16 range / is NaN (checked on the fp32 value in the epilogue)
     constexpr float kF16Max = 65504.f;
 
@@ -536,7 +548,10 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
             for (int m = 0; m < MF; ++m) xaddr[m] = xbuf_a + xb * C::XBUF + (unsigned)xbase[m];
             constexpr int NPLM = C::NPLM;
-            half8 xc[NPLM][MF], xn[NPLM][MF], wr[2][NPLM];
+            // distance 2 pays only where it costs no spills and the MFMA groups are short (r2y: merge_conv_b -1.4 %, merge_conv_a 0, conv4 +10 %)
+            constexpr int WD = (SN_WDIST == 2 && EPI == EPI_FINAL && SPLIT == 2) ? 2 : 1;
+            static_assert(WD == 1 || WD == 2, "weight prefetch distance");
+            half8 xc[NPLM][MF], xn[NPLM][MF], wr[WD + 1][NPLM];
             int ko1, ko2;
             auto issue_x = [&](half8(&dst)[NPLM][MF], int ko) {
                 if constexpr (SN_ABL & 32) return;
@@ -576,24 +591,34 @@ conv3d_f16_mfma(ConvArgs a)
                 v4i x8h[SPLIT == 2 ? MF : 1][2];
                 lds_read128<0>(wr[0][0], wp);
                 if constexpr (SPLIT == 1) lds_read128<1024>(wr[0][1], wp);
-                // next weight piece: the following piece of this slab, else the first piece of what comes next
-                if (p + 1 < npiece) {
-                    const int rem = wchunk - (ch0 + C::PCH);
-                    stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
-                } else if (have_next) {
-                    const int nch = wchunks_of(nc8n);
-                    stage_w(nwoff, nch < C::PCH ? nch : C::PCH, wbi ^ 1);
+                if constexpr (WD == 2 && C::PCH * NF > 1) {
+                    lds_read128<C::MFRAG>(wr[1][0], wp);
+                    if constexpr (SPLIT == 1) lds_read128<C::MFRAG + 1024>(wr[1][1], wp);
                 }
+                // next weight piece (the following piece of this slab, else the first piece of what comes next) and, behind it, the next
+                // slab's halo tile. SN_DMA_LATE: issued AFTER the first MFMA group of the piece instead of in front of it - every wave of the
+                // workgroup leaves the barrier at the same moment, so DMA issue code in front of the first MFMAs idles the matrix pipe of all
+                // four SIMDs for its whole length; behind the first group it runs under those MFMAs.
                 int hnow = 0;
-                if constexpr (BUFH) {
-                    if (have_next && !(SN_ABL & 1) && p == 0)
-                        hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
-                } else if (have_next && !(SN_ABL & 1) && hdone < HT && (p + 1 < npiece || npiece == 1)) {
-                    const int left = HT - hdone;
-                    const int kn = (p + 2 >= npiece || left < HQ) ? left : HQ;
-                    hnow = stage_halo(ntile, nc0, nc8n, xb ^ 1, hdone, kn);
-                    hdone += kn;
-                }
+                auto issue_dmas = [&]() {
+                    if (p + 1 < npiece) {
+                        const int rem = wchunk - (ch0 + C::PCH);
+                        stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
+                    } else if (have_next) {
+                        const int nch = wchunks_of(nc8n);
+                        stage_w(nwoff, nch < C::PCH ? nch : C::PCH, wbi ^ 1);
+                    }
+                    if constexpr (BUFH) {
+                        if (have_next && !(SN_ABL & 1) && p == 0)
+                            hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                    } else if (have_next && !(SN_ABL & 1) && hdone < HT && (p + 1 < npiece || npiece == 1)) {
+                        const int left = HT - hdone;
+                        const int kn = (p + 2 >= npiece || left < HQ) ? left : HQ;
+                        hnow = stage_halo(ntile, nc0, nc8n, xb ^ 1, hdone, kn);
+                        hdone += kn;
+                    }
+                };
+                if constexpr (!SN_DMA_LATE) issue_dmas();
                 static_for<0, C::PCH>([&](auto ccc) {
                     constexpr int cc = decltype(ccc)::value;
                     const int ch = ch0 + cc;
@@ -601,14 +626,26 @@ conv3d_f16_mfma(ConvArgs a)
                         constexpr int par0 = (cc * NF) & 1;
                         static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
-                            constexpr int cur = (par0 + n) & 1, nxt = cur ^ 1;
+                            constexpr int G = cc * NF + n, GT = C::PCH * NF;                     // group index inside the piece / groups of a full piece
+                            constexpr int cur = WD == 2 ? G % 3 : (par0 + n) & 1, nxt = WD == 2 ? (G + 2) % 3 : cur ^ 1;
                             constexpr bool more_n = (n + 1 < NF), more_c = (cc + 1 < C::PCH);
-                            constexpr int wo = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::MFRAG;
-                            if constexpr ((more_n || more_c) && !(SN_ABL & 16)) {
-                                lds_read128<wo>(wr[nxt][0], wp);
-                                if constexpr (SPLIT == 1) lds_read128<wo + 1024>(wr[nxt][1], wp);
+                            // reads issued after this group's fragment and allowed to stay in flight while it is waited for: the fragments of the next
+                            // WD groups, plus (E) the tap offset / activation fragments [/ MX operands] that group 0 of the chunk issues behind its MFMAs
+                            constexpr int E = 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? (SN_MX_B128 ? 2 : 4) * MF + 1 : 0);
+                            if constexpr (WD == 2) {
+                                if constexpr (G + 2 < GT && !(SN_ABL & 16)) {
+                                    lds_read128<(G + 2) * C::MFRAG>(wr[nxt][0], wp);
+                                    if constexpr (SPLIT == 1) lds_read128<(G + 2) * C::MFRAG + 1024>(wr[nxt][1], wp);
+                                }
+                                lgkm_wait<NPLM * ((G + 1 < GT ? 1 : 0) + (G + 2 < GT ? 1 : 0)) + ((n == 1 || n == 2) ? E : 0)>();
+                            } else {
+                                constexpr int wo = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::MFRAG;
+                                if constexpr ((more_n || more_c) && !(SN_ABL & 16)) {
+                                    lds_read128<wo>(wr[nxt][0], wp);
+                                    if constexpr (SPLIT == 1) lds_read128<wo + 1024>(wr[nxt][1], wp);
+                                }
+                                lgkm_wait<((more_n || more_c) ? NPLM : 0) + (n == 1 ? E : 0)>();
                             }
-                            lgkm_wait<((more_n || more_c) ? NPLM : 0) + (n == 1 ? 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? (SN_MX_B128 ? 2 : 4) * MF + 1 : 0) : 0)>();
                             if constexpr (!(SN_ABL & 4)) {
                                 if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(1);
                                 if constexpr (SPLIT == 1) {
@@ -626,6 +663,7 @@ conv3d_f16_mfma(ConvArgs a)
                             } else {
                                 asm volatile("" ::"v"(wr[cur][0]), "v"(xc[0][0]));
                             }
+                            if constexpr (SN_DMA_LATE && cc == 0 && n == 0) issue_dmas();
                             if constexpr (n == 0) {
                                 lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
                                 issue_x(xn, ko1);
@@ -651,7 +689,12 @@ conv3d_f16_mfma(ConvArgs a)
                                 }
                             }
                         });
-                        lgkm_wait<(cc + 1 < C::PCH) ? NPLM : 0>();   // X(c+1), koff(c+2) landed; W(c+1,0) may be in flight
+                        // X(c+1), koff(c+2) [, MX operands] landed (the reads E of group 0); of the next chunk's first WD weight fragments those issued
+                        // AFTER E may still be in flight: fragment j of the next chunk is issued at the start of group NF + j - WD of this one
+                        constexpr int GTc = C::PCH * NF;
+                        constexpr int young = WD == 2 ? ((NF >= 3 && (cc + 1) * NF < GTc ? 1 : 0) + (NF >= 2 && (cc + 1) * NF + 1 < GTc ? 1 : 0))
+                                                      : ((cc + 1 < C::PCH && NF >= 2) ? 1 : 0);
+                        lgkm_wait<NPLM * young>();
 #pragma unroll
                         for (int m = 0; m < MF; ++m) {
                             xc[0][m] = xn[0][m];
@@ -698,10 +741,23 @@ conv3d_f16_mfma(ConvArgs a)
                 });
                 lgkm_wait<0>();
                 if constexpr (!(SN_ABL & 2)) {
+                    long long tq0 = 0, tq1 = 0;
+                    if constexpr (SN_TIMING) { tq0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                     // next weight piece landed; the newest HQ halo DMAs (issued after it) may still fly
                     if (p + 1 != npiece && hnow >= HQ) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HQ) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if constexpr (SN_TIMING) { tq1 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                     wg_barrier();                             // ... for every wave; this piece's buffers are free again
+                    if constexpr (SN_TIMING) {
+                        const long long tq2 = __builtin_readcyclecounter();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        t_vm += tq1 - tq0; t_bar += tq2 - tq1;
+                        if (EPI == EPI_FINAL && a.status && blockIdx.x == 0 && n_piece < 2048 && lane == 0) {     // trace of workgroup 0: [piece][wave]{arrive, release}
+                            long long *tr = reinterpret_cast<long long *>(a.status + 2 + 32 * 8) + ((size_t)n_piece * C::NW + wave) * 2;
+                            tr[0] = tq1; tr[1] = tq2;
+                        }
+                        ++n_piece;
+                    }
                 }
                 wbi ^= 1;
             }
@@ -1019,6 +1075,13 @@ conv3d_f16_mfma(ConvArgs a)
         }
     }
     if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, a.status_bit);
+    if constexpr (SN_TIMING) {
+        if (a.status && lane == 0) {        // [2..9]: per layer-bit slot of 4 x u64: kernel cycles, vmcnt-wait cycles, barrier-wait cycles, pieces (summed over waves)
+            unsigned long long *t = reinterpret_cast<unsigned long long *>(a.status + 2) + 4 * (31 - __builtin_clz(a.status_bit));
+            atomicAdd(t + 0, (unsigned long long)(__builtin_readcyclecounter() - t_kernel0));
+            atomicAdd(t + 1, (unsigned long long)t_vm); atomicAdd(t + 2, (unsigned long long)t_bar); atomicAdd(t + 3, (unsigned long long)n_piece);
+        }
+    }
 }
 
 }  // namespace sn

@@ -396,7 +396,7 @@ static int create_impl(sn_ctx *c)
     int rc;
 #define AL(p, n) do { if ((rc = dev_alloc(c, &c->p, (n))) != SN_OK) return rc; } while (0)
     AL(unf_ws, S * v1); AL(d_fused, S * v1);
-    AL(d_num, 1); HIPCHK(hipMemset(c->d_num, 0, sizeof(unsigned)));
+    AL(d_num, 2 + 32 * 8 + 2048 * 8 * 4); HIPCHK(hipMemset(c->d_num, 0, sizeof(unsigned) * (2 + 32 * 8 + 2048 * 8 * 4)));     // [0] status bits; [2..] SN_TIMING diagnostic slots
     AL(d_pairs, S * 2); AL(d_xyz, S * 3); AL(d_resol, S); AL(d_w, S);
 #undef AL
     return SN_OK;
@@ -1044,6 +1044,29 @@ int sn_memcpy_d2h(sn_ctx *c, void *dst, const void *src, size_t bytes)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
+// Diagnostic builds only (-DSN_TIMING=1, conv3d_mfma.h): per-layer shader-clock totals {kernel, vmcnt wait, barrier wait, pieces} summed over
+// waves, in layer-bit order (names: sn_synchronize's message order). Not part of the ABI header; reads and clears the slots.
+int sn_debug_timing(sn_ctx *c, unsigned long long *out, int n_layers, char *names, int names_cap)
+{
+    if (!c || !out || !c->d_num) return fail(SN_ERR_ARG, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    n_layers = std::min(n_layers, 32);
+    HIPCHK(hipMemcpy(out, c->d_num + 2, sizeof(unsigned long long) * 4 * n_layers, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->d_num + 2, 0, sizeof(unsigned) * 32 * 8));
+    std::string all;
+    for (auto &nm : c->num_names) all += nm + ",";
+    if (names && names_cap > 0) { strncpy(names, all.c_str(), names_cap - 1); names[names_cap - 1] = 0; }
+    return SN_OK;
+}
+// workgroup 0 of the last EPI_FINAL launch: [2048 pieces][8 waves]{arrival at the barrier, release} shader clocks
+int sn_debug_trace(sn_ctx *c, long long *out)
+{
+    if (!c || !out || !c->d_num) return fail(SN_ERR_ARG, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->d_num + 2 + 32 * 8, sizeof(long long) * 2048 * 8 * 2, hipMemcpyDeviceToHost));
     return SN_OK;
 }
 
