@@ -349,3 +349,27 @@ def test_repeated_full_batches_are_bit_identical(sn):
                 assert np.array_equal(f, first_f) and np.array_equal(u, first_u), "pass %d differs from pass 0" % it
         other.synchronize(); ctx.synchronize()
         assert np.isfinite(first_u).all() and first_u.std() > 0.01
+
+
+def test_epilogue_fusion_equals_separate_launches(gpu_required, tmp_path):
+    """conv1_3 / conv2_3 with side_op1/2 and the max-pools in their epilogue (EPI_SIDEPOOL) against the three separate launches
+    (SN_NO_EPI_FUSION=1, read once per process -> two subprocesses). The pooled tensors are bit-identical by construction; the side
+    convolution sums its 32 / 80 products in a different order inside the MFMA, so the final probabilities agree to fp32 rounding."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("", "1"):
+        env = dict(os.environ)
+        env.pop("SN_NO_EPI_FUSION", None)
+        if flag:
+            env["SN_NO_EPI_FUSION"] = flag
+        out = str(tmp_path / ("o%s.npz" % flag))
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "ab_outputs.py"), "save", out], env=env, cwd=root)
+        outs.append(np.load(out))
+    for k in outs[0].files:
+        a, b = outs[0][k], outs[1][k]
+        # f16x3: fp32-class; f16m8: the stand-alone side kernel computes in f16m8, the fused one on three fp16 MFMAs; f16: fp16-class
+        tol = 2e-3 if "_f16_" in k else (2e-4 if "_f16m8_" in k else 2e-5)
+        assert a.shape == b.shape and np.abs(a - b).max() < tol, (k, float(np.abs(a - b).max()))
