@@ -1,0 +1,191 @@
+"""oracle/net_emulation.py — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A CPU MODEL OF THE HIP PATH'S ARITHMETIC (not of the reference): the same network as net_oracle.forward_torch, computed in float64
+but with every rounding the device applies in its two MX-assisted modes, so that a parity test can tell "the kernel does what its
+design says" (device vs this model: ~1e-5) apart from "the design is accurate enough" (this model vs the exact oracle: ~1e-4).
+
+What is modelled (surfacenet_amd/csrc/mx_format.h, conv3d_mfma.h, sn_api.hip pack_conv / sn_load_weights):
+  * exact power-of-two renormalisation: a ReLU layer stores y * 2^oe[c], oe = -ilogb(max(|gamma|, |beta|)); its consumer's weights are
+    multiplied by 2^-oe[c_in] and every weight row by 2^row_exp, row_exp = -ilogb(max |row|) — exact, but it decides where the 6-bit
+    codes saturate or flush;
+  * storage "x3": value = hi + fp16(value - hi), hi = fp16(value);   storage "m6": hi + q6((value - hi) * 2^11 * 2^s) / 2^(11+s);
+  * product "m6" (f16m8 arithmetic): w*x = wh*xh  +  q6b(wl * 2^11) / 2^11 * q6(xh * 2^s) / 2^s  +  q6b(wh) * lo6,
+    q6 = fp6 e2m3 (round to nearest even, saturating at 7.5, subnormal step 0.125), q6b = the same with one power-of-two scale per
+    weight block (one output channel x 8 input channels x two consecutive K groups: tap pairs (0,1), (2,3) .. for the 3x3x3 layers,
+    channel-group pairs inside a 5-group slab for the 1x1x1 layers);
+  * product "x3": exact on the stored values (the device drops lo*lo, 2^-22 relative, and accumulates in fp32).
+mode "f16x3" (the default): everything "x3" except the concat buffer and merge_conv_a's output (storage m6, premultipliers s = 2 / 0)
+and merge_conv_a / merge_conv_b (product m6); conv1_3 / conv2_3 feed their side conv and pool from unrounded registers.
+mode "f16m8": every tensor m6, every conv product m6 (the network input with s = -5)."""
+import numpy as np
+
+from oracle import net_oracle
+
+LO_EXP = 11
+S_ACT, S_CAT, S_X0 = 0, 2, -5
+
+
+def _ilogb(a):
+    a = np.asarray(a, dtype=np.float64)
+    out = np.zeros(a.shape, dtype=np.int64)
+    nz = a > 0
+    out[nz] = np.floor(np.log2(a[nz])).astype(np.int64)
+    # guard against log2 rounding at exact powers of two
+    out[nz] += (np.ldexp(1.0, out[nz] + 1) <= a[nz]).astype(np.int64)
+    out[nz] -= (np.ldexp(1.0, out[nz]) > a[nz]).astype(np.int64)
+    return out
+
+
+def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
+    import torch
+    import torch.nn.functional as F
+    assert mode in ("f16x3", "f16m8")
+    td = torch.float64
+    P = net_oracle.params_to_dict(values)
+    full = mode == "f16m8"
+
+    def f16(t):
+        return t.to(torch.float16).to(td)
+
+    def q6(v):
+        """fp6 e2m3 of v (already premultiplied): RNE, saturating, subnormals."""
+        a = v.abs().clamp(max=7.5)
+        step = torch.where(a < 2, torch.full_like(a, 0.125), torch.where(a < 4, torch.full_like(a, 0.25), torch.full_like(a, 0.5)))
+        return torch.sign(v) * torch.round(a / step) * step
+
+    class T:  # a stored activation tensor in ORIGINAL units + how the device holds it
+        def __init__(self, v, oe, fmt, s):
+            self.oe = torch.from_numpy(np.asarray(oe, dtype=np.float64)).view(1, -1, 1, 1, 1)      # stored = v * 2^oe
+            r = v * torch.exp2(self.oe)
+            self.hi = f16(r)
+            if fmt == "x3":
+                self.lo = f16(r - self.hi)
+            else:
+                self.lo = q6((r - self.hi) * 2.0 ** (LO_EXP + s)) / 2.0 ** (LO_EXP + s)
+            self.fmt, self.s = fmt, s
+            self.v = (self.hi + self.lo) / torch.exp2(self.oe)                                         # what a reader reconstructs
+
+    def block_q6(wh, wl, kind, cin):
+        """wh, wl*2^11: (O, Cp, T) renormalised weights, Cp = cin padded to 8. -> their 6-bit block-scaled values."""
+        O, Cp, Tn = wh.shape
+        G = Cp // 8
+        a, b = wh.reshape(O, G, 8, Tn), wl.reshape(O, G, 8, Tn)
+        if Tn > 1:                                   # 3x3x3: one channel group per slab, K groups = taps, blocks = tap pairs
+            Tp = Tn + (Tn & 1)
+            pad = lambda z: torch.cat([z, torch.zeros(O, G, 8, Tp - Tn, dtype=td)], dim=3)
+            a, b = pad(a).reshape(O, G, 8, Tp // 2, 2), pad(b).reshape(O, G, 8, Tp // 2, 2)
+            amax = torch.maximum(a.abs().amax(dim=(2, 4)), b.abs().amax(dim=(2, 4)))                   # (O, G, Tp/2)
+            E = block_exp(amax).view(O, G, 1, Tp // 2, 1)
+            aq, bq = q6(a / 2.0 ** E) * 2.0 ** E, q6(b / 2.0 ** E) * 2.0 ** E
+            return aq.reshape(O, G, 8, Tp)[..., :Tn].reshape(O, Cp, Tn), bq.reshape(O, G, 8, Tp)[..., :Tn].reshape(O, Cp, Tn)
+        # 1x1x1: slabs of up to 5 channel groups (tile_for), blocks = consecutive group pairs inside a slab
+        aq, bq = torch.zeros_like(a), torch.zeros_like(b)
+        g0 = 0
+        while g0 < G:
+            n = min(5, G - g0)
+            for j in range(0, n, 2):
+                sl = slice(g0 + j, min(g0 + j + 2, g0 + n))
+                amax = torch.maximum(a[:, sl].abs().amax(dim=(1, 2, 3)), b[:, sl].abs().amax(dim=(1, 2, 3)))
+                E = block_exp(amax).view(O, 1, 1, 1)
+                aq[:, sl], bq[:, sl] = q6(a[:, sl] / 2.0 ** E) * 2.0 ** E, q6(b[:, sl] / 2.0 ** E) * 2.0 ** E
+            g0 += n
+        return aq.reshape(O, Cp, Tn), bq.reshape(O, Cp, Tn)
+
+    def block_exp(amax):
+        am = amax.numpy()
+        E = _ilogb(am / 7.5)
+        E = E + (np.ldexp(am, -E) > 7.5)
+        E[am == 0] = 0
+        return torch.from_numpy(E.astype(np.float64))
+
+    def conv(x, name, kind, act, prod, store_fmt, store_s=S_ACT, keep_unrounded=False):
+        """x: T (or a raw tensor for unrounded register inputs). Returns T (stored) [, unrounded output]."""
+        p = P[name]
+        W = p["W"].astype(np.float64)
+        if kind in ("dil3", "dil1"):
+            W = np.transpose(W, (1, 0, 2, 3, 4))
+        O, C, k = W.shape[0], W.shape[1], W.shape[2]
+
+        def cv(xx, ww):
+            ww = ww.reshape(O, -1, k, k, k)[:, :C]
+            if kind == "dil3":
+                return F.conv3d(F.pad(xx, (2,) * 6), ww, dilation=2)
+            return F.conv3d(xx, ww, padding=k // 2)
+
+        raw = not isinstance(x, T)
+        oe_in = torch.zeros(1, C, 1, 1, 1, dtype=td) if raw else x.oe
+        Wt = torch.from_numpy(np.ascontiguousarray(W)).to(td).reshape(O, C, -1)
+        if prod == "x3":
+            xv = x if raw else x.v
+            wh = f16(Wt)
+            y = cv(xv, wh + f16(Wt - wh))
+        else:
+            # renormalised weights: W' = W * 2^-oe_in[c] * 2^row_exp[o]
+            Wr = Wt / torch.exp2(oe_in.view(1, C, 1))
+            row = torch.from_numpy(-_ilogb(Wr.abs().amax(dim=(1, 2)).numpy()).astype(np.float64)).view(O, 1, 1)
+            Wr = Wr * torch.exp2(row)
+            Cp = (C + 7) // 8 * 8
+            Wr = torch.cat([Wr, torch.zeros(O, Cp - C, Wr.shape[2], dtype=td)], dim=1)
+            wh = f16(Wr)
+            wh6, wl6 = block_q6(wh, (Wr - wh) * 2.0 ** LO_EXP, kind, C)
+            wl6 = wl6 / 2.0 ** LO_EXP
+            xh6 = q6(x.hi * 2.0 ** x.s) / 2.0 ** x.s                        # renormalised units
+            # all three terms in renormalised units, then undo the row exponent (the input exponent is inside W')
+            y = (cv(x.hi, wh) + cv(xh6, wl6) + cv(x.lo, wh6)) / torch.exp2(row.view(1, O, 1, 1, 1))
+        scale = (p["gamma"].astype(np.float64) * p["inv_std"].astype(np.float64)).astype(np.float32)
+        shift = (p["beta"].astype(np.float64) - p["mean"].astype(np.float64) * scale.astype(np.float64)).astype(np.float32)
+        y = y.to(torch.float32) * torch.from_numpy(scale).view(1, -1, 1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1, 1)
+        y = (torch.relu(y) if act == "relu" else torch.sigmoid(y)).to(td)
+        oe = np.zeros(O)
+        if act == "relu":
+            m = np.maximum(np.abs(p["gamma"].astype(np.float64)), np.abs(p["beta"].astype(np.float64)))
+            oe = np.clip(-_ilogb(m), -60, 60).astype(np.float64)
+            oe[~(m > 0)] = 0
+        if store_fmt is None:
+            return y
+        out = T(y, oe, store_fmt, store_s)
+        return (out, y, oe) if keep_unrounded else out
+
+    def up(x, name, f):
+        k = P[name]["W"].shape[2]
+        Wk = torch.from_numpy(np.ascontiguousarray(P[name]["W"])).to(td)
+        B, C = x.shape[:2]
+        z = torch.zeros((B, C, x.shape[2] * f, x.shape[3] * f, x.shape[4] * f), dtype=td)
+        z[:, :, ::f, ::f, ::f] = x
+        return F.conv3d(z.reshape(B * C, 1, *z.shape[2:]), Wk, padding=k // 2).reshape(B, C, *z.shape[2:])
+
+    A = "m6" if full else "x3"          # arithmetic / storage of the layers upstream of the concat buffer
+    x = T(torch.from_numpy(np.ascontiguousarray(X)).to(td), np.zeros(X.shape[1]), A, S_X0)
+    c11 = conv(x, "conv1_1", "conv3", "relu", A, A)
+    c12 = conv(c11, "conv1_2", "conv3", "relu", A, A)
+    c13, y13, oe13 = conv(c12, "conv1_3", "conv3", "relu", A, A, keep_unrounded=True)
+    # conv1_3 / conv2_3: side conv and pool run on the unrounded registers; the pooled tensor is stored in the layer's own format
+    s1 = conv(y13, "side_op1", "conv1", "sigmoid", "x3", None)
+    p1 = T(F.max_pool3d(y13, 2, 2), oe13, A, S_ACT)
+    c21 = conv(p1, "conv2_1", "conv3", "relu", A, A)
+    c22 = conv(c21, "conv2_2", "conv3", "relu", A, A)
+    c23, y23, oe23 = conv(c22, "conv2_3", "conv3", "relu", A, A, keep_unrounded=True)
+    s2 = T(conv(y23, "side_op2", "conv1", "sigmoid", "x3", None), np.zeros(16), A, S_ACT)
+    p2 = T(F.max_pool3d(y23, 2, 2), oe23, A, S_ACT)
+    c31 = conv(p2, "conv3_1", "conv3", "relu", A, A)
+    c32 = conv(c31, "conv3_2", "conv3", "relu", A, A)
+    c33 = conv(c32, "conv3_3", "conv3", "relu", A, A)
+    s3 = conv(c33, "side_op3", "conv1", "sigmoid", A, A)
+    c41 = conv(c33, "conv4_1", "dil3", "relu", A, A)
+    c42 = conv(c41, "conv4_2", "dil3", "relu", A, A)
+    c43 = conv(c42, "conv4_3", "dil3", "relu", A, A)
+    s4 = conv(c43, "side_op4", "dil1", "sigmoid", A, A)
+    cat_v = torch.cat([s1, up(s2.v, "side_op2_deconv", 2), up(s3.v, "side_op3_deconv", 4), up(s4.v, "side_op4_deconv", 4)], dim=1)
+    cat = T(cat_v, np.zeros(64), "m6", S_CAT)
+    ma = conv(cat, "merge_conv_a", "conv3", "relu", "m6", "m6", S_ACT)
+    mb = conv(ma, "merge_conv_b", "conv3", "relu", "m6", None)                    # stays in fp32 registers
+    p3 = P["merge_conv3"]
+    w3 = torch.from_numpy(np.ascontiguousarray(p3["W"].astype(np.float64))).to(td)
+    y = F.conv3d(mb, w3)
+    scale = (p3["gamma"].astype(np.float64) * p3["inv_std"].astype(np.float64)).astype(np.float32)
+    shift = (p3["beta"].astype(np.float64) - p3["mean"].astype(np.float64) * scale.astype(np.float64)).astype(np.float32)
+    out = torch.sigmoid(y.to(torch.float32) * float(scale[0]) + float(shift[0])).to(td)
+    unf = out.numpy().astype(np.float64)
+    s = X.shape[-1]
+    unfused = unf.reshape(-1, n_vp, s, s, s)
+    return net_oracle.fuse(unfused, w, n_vp), unfused

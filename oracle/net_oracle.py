@@ -96,8 +96,7 @@ def _sigmoid(x):
 # quant = "fp16"          -> emulates the HIP path's storage precision: weights and every stored
 #                            activation are rounded to IEEE half, products accumulate wide, BN affine +
 #                            activation are applied in fp32 before the rounding
-# quant = "f16m8"         -> emulates the f16m8 mode: stored value = hi + lo8 with hi = fp16(v), lo8 = fp8_e4m3((v-hi)*2^12)/2^12;
-#                            w*x = wh*xh (fp16) + fp8(wl*2^12)/2^12 * fp8(xh) + fp8(wh) * lo8   (wl = w - wh)
+#                            (the MX-assisted modes of the HIP path are modelled in oracle/net_emulation.py)
 # ------------------------------------------------------------------------------------------------
 def forward_torch(X, values, w=None, n_vp=1, quant=None, dtype="float64", return_intermediates=False):
     import torch
@@ -105,15 +104,9 @@ def forward_torch(X, values, w=None, n_vp=1, quant=None, dtype="float64", return
     td = getattr(torch, dtype)
     P = params_to_dict(values)
 
-    def f8(t):
-        return t.clamp(-448, 448).to(torch.float32).to(torch.float8_e4m3fn).to(td)
-
     def q(t):
         if quant == "fp16":
             return t.to(torch.float16).to(td)
-        if quant == "f16m8":
-            hi = t.to(torch.float16).to(td)
-            return hi + f8((t - hi) * 4096.0) / 4096.0
         return t
 
     def tw(a):
@@ -123,7 +116,7 @@ def forward_torch(X, values, w=None, n_vp=1, quant=None, dtype="float64", return
     def bn_act(y, p, act):
         scale = (p["gamma"].astype(np.float64) * p["inv_std"].astype(np.float64))
         shift = p["beta"].astype(np.float64) - p["mean"].astype(np.float64) * scale
-        if quant in ("fp16", "f16m8"):  # the device applies fp32 scale/shift in the conv epilogue
+        if quant == "fp16":  # the device applies fp32 scale/shift in the conv epilogue
             scale = scale.astype(np.float32); shift = shift.astype(np.float32)
             y = y.to(torch.float32)
             y = y * torch.from_numpy(scale).view(1, -1, 1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1, 1)
@@ -143,14 +136,7 @@ def forward_torch(X, values, w=None, n_vp=1, quant=None, dtype="float64", return
                 return F.conv3d(F.pad(xx, (2,) * 6), ww, dilation=2)  # PadLayer(2) + 'valid' dilated conv
             return F.conv3d(xx, ww, padding=k // 2)
 
-        if quant == "f16m8" and store is not None and name != "merge_conv3":
-            Wt = torch.from_numpy(np.ascontiguousarray(W)).to(td)
-            wh = Wt.to(torch.float16).to(td)
-            wl8 = f8((Wt - wh) * 4096.0) / 4096.0
-            xh = x.to(torch.float16).to(td)
-            y = cv(xh, wh) + cv(f8(xh), wl8) + cv(x - xh, f8(wh))
-        else:
-            y = cv(x, tw(W) if name != "merge_conv3" or quant != "f16m8" else torch.from_numpy(np.ascontiguousarray(W)).to(td))
+        y = cv(x, tw(W))
         y = bn_act(y, p, act)
         return q(y) if store else y
 

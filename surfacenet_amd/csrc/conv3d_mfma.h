@@ -41,6 +41,7 @@
 //     [w*XS, (w+1)*XS) and all NF channel fragments, so the 1x1x1 reduction of merge_conv3 stays inside a wave.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "mx_format.h"
 #include <stdint.h>
 #include <type_traits>
 
@@ -119,6 +120,8 @@ struct ConvArgs {
     int in_cs, out_cs, out_coff, out_cp;
     int D, DX, tiles_x, tiles_y, tiles_z, total_tiles;   // volume = DX x D x D voxels (3-D nets: DX = D; 2-D nets: x = image index)
     int act;              // 0 relu, 1 sigmoid
+    int mx_in_e8, mx_out_e8, mx_side_e8;   // 6-bit MX forms (mx_format.h): E8M0 exponent 127 - s of the static premultiplier of the code planes
+                                           // of the input tensor / of out and pool_out / of side_out
     int stagger_clk;      // start delay (shader clocks) per phase step: workgroups start in 4 phases so that their
                           // epilogue store bursts do not hit HBM at the same instant (0 = off)
     int nslab;
@@ -169,6 +172,20 @@ template <int OFF>
 __device__ __forceinline__ void lds_read128i(v4i &d, unsigned addr)
 {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+typedef int v3i __attribute__((ext_vector_type(3)));
+template <int OFF>
+__device__ __forceinline__ void lds_read96i(v3i &d, unsigned addr)
+{
+    asm volatile("ds_read_b96 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+// one 48-bit code unit (4 channels: hi x4, lo x4; mx_format.h) -> bytes [6*half, 6*half+6) of a slot (half-slot writers of the pooling epilogues)
+__device__ __forceinline__ void sn_mx6_store_unit(char *slot, int half, const _Float16 (&h)[4], const float (&lo)[4], int e8)
+{
+    unsigned w[2][2];
+    sn_mx6_units(h, lo, h, lo, e8, w);
+    unsigned short *d = reinterpret_cast<unsigned short *>(slot) + 3 * half;
+    d[0] = (unsigned short)w[0][0]; d[1] = (unsigned short)(w[0][0] >> 16); d[2] = (unsigned short)w[0][1];
 }
 // fp8 e4m3 pack of four fp32 values (round-to-nearest-even, saturating at +-448)
 __device__ __forceinline__ int sn_pack_fp8x4(float a, float b, float c, float d)
@@ -262,6 +279,8 @@ conv3d_f16_mfma(ConvArgs a)
     // loop and LDS-DMA destination indexed by it becomes an EXEC-masked (waterfall) loop (guide T20)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v = lane & 15, kq = lane >> 4;
+    int mx_sb = a.mx_in_e8;                                  // scale operand of the MX step's activation side (6-bit forms): loaded once, kept in a VGPR
+    if constexpr (SPLIT == 2 && SN_MX_FMT != 0) asm volatile("" : "+v"(mx_sb));
     const int D = a.D, DX = a.DX;
     const size_t VOL = (size_t)DX * D * D;
     const int tstride = gridDim.x;
@@ -589,6 +608,7 @@ conv3d_f16_mfma(ConvArgs a)
                 v8i x8[SPLIT == 2 ? MF : 1];
                 long long x8q[SPLIT == 2 ? MF : 1][4];
                 v4i x8h[SPLIT == 2 ? MF : 1][2];
+                v3i x6[SPLIT == 2 ? MF : 1][2];                                    // 6-bit forms: a slot's 12 code bytes
                 lds_read128<0>(wr[0][0], wp);
                 if constexpr (SPLIT == 1) lds_read128<1024>(wr[0][1], wp);
                 if constexpr (WD == 2 && C::PCH * NF > 1) {
@@ -672,7 +692,11 @@ conv3d_f16_mfma(ConvArgs a)
                                     // piece ahead); also fetch the next piece's tap offsets
                                     static_for<0, MF>([&](auto mc) {
                                         constexpr int m = decltype(mc)::value;
-                                        if constexpr (SN_MX_B128) {
+                                        if constexpr (SN_MX_B128 && SN_MX_FMT != 0) {
+                                            const unsigned ad = xaddr[m] + C::XPLANE;               // the 12 code bytes of two slots = the lane's 192-bit operand
+                                            lds_read96i<0>(x6[m][0], ad + (unsigned)(int)k2);
+                                            lds_read96i<0>(x6[m][1], ad + (unsigned)(int)(k2 >> 32));
+                                        } else if constexpr (SN_MX_B128) {
                                             const unsigned ad = xaddr[m] + C::XPLANE;               // whole 16-byte slots [fp8(hi) x8 | fp8(lo*2^12) x8]
                                             lds_read128i<0>(x8h[m][0], ad + (unsigned)(int)k2);
                                             lds_read128i<0>(x8h[m][1], ad + (unsigned)(int)(k2 >> 32));
@@ -709,7 +733,11 @@ conv3d_f16_mfma(ConvArgs a)
                         constexpr int mxo = 2 * NF * 1024;
     #pragma unroll
                         for (int m = 0; m < MF; ++m) {
-                            if constexpr (SN_MX_B128) {
+                            if constexpr (SN_MX_B128 && SN_MX_FMT != 0) {
+                                // the second slot's three dwords cannot be read in place (a register tuple starts on an even register): 3 v_mov's per
+                                // fragment. Tried: reading it as 32 + 64 bits (lands in place, but the 64-bit read is 4-byte aligned) - merge_conv_b +23 %
+                                x8[m] = __builtin_shufflevector(x6[m][0], x6[m][1], 0, 1, 2, 3, 4, 5, -1, -1);
+                            } else if constexpr (SN_MX_B128) {
                                 x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 3, 4, 5, 6, 7);
                             } else {
                                 x8[m][0] = (int)x8q[m][0]; x8[m][1] = (int)(x8q[m][0] >> 32); x8[m][2] = (int)x8q[m][1]; x8[m][3] = (int)(x8q[m][1] >> 32);
@@ -717,6 +745,36 @@ conv3d_f16_mfma(ConvArgs a)
                             }
                         }
                         if constexpr (SN_MX_B128) k2 = k2n; else k4 = k4n;
+                        if constexpr (SN_MX_FMT != 0) {
+                            // 6-bit operands: the weight fragment of a lane is its 192-bit operand, dwords 0..3 in the first lane-linear KiB of the
+                            // fragment and 4..5 in the second: a 128-bit and a 64-bit read into 6 consecutive registers (register tuples start on even
+                            // registers, so any other split costs v_mov's). The E8M0 block scales of the lane's NF fragments are the 8 bytes behind
+                            // dwords 4..5 of fragment 0: one 64-bit read per piece, the byte is picked by the instruction's op_sel (pack_conv).
+                            static_assert(SN_MX_B128 && NF <= 8, "the 6-bit MX forms use the two-slot operand layout");
+                            v4i wa4[2];
+                            long long wb2[2], wsc;
+                            lds_read64<mxo + 1024 + 8>(wsc, wp);
+                            lds_read128i<mxo>(wa4[0], wp);
+                            lds_read64<mxo + 1024>(wb2[0], wp);
+                            static_for<0, NF>([&](auto nc) {
+                                constexpr int n = decltype(nc)::value;
+                                constexpr int cur = n & 1, nxt = cur ^ 1;
+                                if constexpr (n + 1 < NF) {
+                                    lds_read128i<mxo + (n + 1) * 2048>(wa4[nxt], wp);
+                                    lds_read64<mxo + (n + 1) * 2048 + 1024>(wb2[nxt], wp);
+                                }
+                                lgkm_wait<(n + 1 < NF) ? 2 : 0>();
+                                v8i wa;
+                                wa[0] = wa4[cur][0]; wa[1] = wa4[cur][1]; wa[2] = wa4[cur][2]; wa[3] = wa4[cur][3];
+                                wa[4] = (int)wb2[cur]; wa[5] = (int)(wb2[cur] >> 32); wa[6] = 0; wa[7] = 0;
+                                const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
+                                if constexpr (!(SN_ABL & (4 | 128))) {
+    #pragma unroll
+                                    for (int m = 0; m < MF; ++m)
+                                        acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
+                                }
+                            });
+                        } else {
                         v4i w8[2][2];
                         lds_read128i<mxo>(w8[0][0], wp);
                         lds_read128i<mxo + 1024>(w8[0][1], wp);
@@ -737,6 +795,7 @@ conv3d_f16_mfma(ConvArgs a)
                                     acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, x8[m], acc[m][n], 0, 0, 0, 115, 0, 127);
                             }
                         });
+                        }
                     }
                 });
                 lgkm_wait<0>();
@@ -807,7 +866,7 @@ conv3d_f16_mfma(ConvArgs a)
                             h[r] = hh; l[r] = ll;
                         } else {
                             h[r] = (_Float16)y;
-                            lo32[r] = (y - (float)h[r]) * 4096.f;
+                            lo32[r] = (y - (float)h[r]) * kMxLoMul;
                         }
                     }
                     if (writer && nl < a.out_cp) {
@@ -817,8 +876,13 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (OSPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
                         if constexpr (OSPLIT == 2) {
                             char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.out_lo_off);
-                            *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                            *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                            if constexpr (SN_MX_FMT != 0) {
+                                const _Float16 hq[4] = {h[0], h[1], h[2], h[3]};
+                                sn_mx6_store_unit(slot, (ch & 7) >> 2, hq, lo32, a.mx_out_e8);
+                            } else {
+                                *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                                *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                            }
                         }
                     }
                 }
@@ -876,6 +940,8 @@ conv3d_f16_mfma(ConvArgs a)
                     bool valid[2];
                     size_t vlin[2];
                     unsigned hw[2][2], lw[2][2];
+                    _Float16 hq[2][4];
+                    float loq[2][4];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         int hx, hy, hz;
@@ -896,7 +962,7 @@ conv3d_f16_mfma(ConvArgs a)
                                 h[r] = hh; l[r] = ll;
                             } else {
                                 h[r] = (_Float16)t;
-                                lo32[r] = (t - (float)h[r]) * 4096.f;
+                                lo32[r] = (t - (float)h[r]) * kMxLoMul;
                             }
                         }
                         const uint2 hb = __builtin_bit_cast(uint2, h);
@@ -904,11 +970,15 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (OSPLIT == 1) {
                             const uint2 lb = __builtin_bit_cast(uint2, l);
                             lw[e][0] = lb.x; lw[e][1] = lb.y;
+                        } else if constexpr (OSPLIT == 2 && SN_MX_FMT != 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { hq[e][r] = h[r]; loq[e][r] = lo32[r]; }
                         } else if constexpr (OSPLIT == 2) {
                             lw[e][0] = (unsigned)sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
                             lw[e][1] = (unsigned)sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
                         }
                     }
+                    if constexpr (OSPLIT == 2 && SN_MX_FMT != 0) sn_mx6_units(hq[0], loq[0], hq[1], loq[1], a.mx_side_e8, lw);
                     const bool st = odd ? valid[1] : valid[0];
                     const size_t my_vlin = odd ? vlin[1] : vlin[0];
                     const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
@@ -923,6 +993,11 @@ conv3d_f16_mfma(ConvArgs a)
                     } else if constexpr (OSPLIT == 2) {
                         const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
                         const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
+                        if constexpr (SN_MX_FMT != 0) {      // lw[e] = {low 32, high 16 bits} of the 48-bit unit of fragment e; [0]: channels 0..3, [1]: 4..7
+                            unsigned d[3];
+                            sn_mx6_join(l0[0], l1[0], l0[1], l1[1], d);
+                            if (st) *reinterpret_cast<u32x4 *>(o + a.side_lo_off) = u32x4{d[0], d[1], d[2], 0u};
+                        } else
                         if (st) *reinterpret_cast<u32x4 *>(o + a.side_lo_off) = u32x4{l0[0], l0[1], l1[0], l1[1]};
                     }
                 }
@@ -951,7 +1026,7 @@ conv3d_f16_mfma(ConvArgs a)
                             h[r] = hh; l[r] = ll;
                         } else {
                             h[r] = (_Float16)t;
-                            lo32[r] = (t - (float)h[r]) * 4096.f;
+                            lo32[r] = (t - (float)h[r]) * kMxLoMul;
                         }
                     }
                     const int ch = n * 16 + kq * 4;
@@ -961,8 +1036,13 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (SPLIT == 1) *reinterpret_cast<half4 *>(o + a.pool_lo_off) = l;
                         if constexpr (SPLIT == 2) {
                             char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.pool_lo_off);
-                            *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                            *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                            if constexpr (SN_MX_FMT != 0) {
+                                const _Float16 hq[4] = {h[0], h[1], h[2], h[3]};
+                                sn_mx6_store_unit(slot, (ch & 7) >> 2, hq, lo32, a.mx_out_e8);
+                            } else {
+                                *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                                *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                            }
                         }
                     }
                 }
@@ -999,6 +1079,8 @@ conv3d_f16_mfma(ConvArgs a)
                     const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.scale + nlc);
                     const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + NF * 16 + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.shift + nlc);
                     unsigned hw[2][2], lw[2][2];                          // [fragment of the pair][dword]: hi plane, second plane
+                    _Float16 hq[2][4];
+                    float loq[2][4];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         half4 h, l;
@@ -1014,7 +1096,7 @@ conv3d_f16_mfma(ConvArgs a)
                                 h[r] = hh; l[r] = ll;
                             } else {
                                 h[r] = (_Float16)y;
-                                lo32[r] = (y - (float)h[r]) * 4096.f;
+                                lo32[r] = (y - (float)h[r]) * kMxLoMul;
                             }
                         }
                         const uint2 hb = __builtin_bit_cast(uint2, h);
@@ -1022,12 +1104,16 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (OSPLIT == 1) {
                             const uint2 lb = __builtin_bit_cast(uint2, l);
                             lw[e][0] = lb.x; lw[e][1] = lb.y;
+                        } else if constexpr (OSPLIT == 2 && SN_MX_FMT != 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { hq[e][r] = h[r]; loq[e][r] = lo32[r]; }
                         } else if constexpr (OSPLIT == 2) {
                             // second plane, 16-byte slot per (voxel, group): [fp8(hi) c0..c7 | fp8(lo*2^12) c0..c7]
                             lw[e][0] = (unsigned)sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
                             lw[e][1] = (unsigned)sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
                         }
                     }
+                    if constexpr (OSPLIT == 2 && SN_MX_FMT != 0) sn_mx6_units(hq[0], loq[0], hq[1], loq[1], a.mx_out_e8, lw);   // mx_format.h
                     // r[0] = {own (even kq) | lower partner's fragment-(m+1) half (odd kq)}, r[1] = {upper partner's fragment-m half | own}
                     const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
                     const auto h1 = __builtin_amdgcn_permlane16_swap(hw[0][1], hw[1][1], false, false);
@@ -1042,6 +1128,11 @@ conv3d_f16_mfma(ConvArgs a)
                     } else if constexpr (OSPLIT == 2) {
                         const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);   // fp8(hi) words
                         const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);   // fp8(lo) words
+                        if constexpr (SN_MX_FMT != 0) {
+                            unsigned d[3];
+                            sn_mx6_join(l0[0], l1[0], l0[1], l1[1], d);
+                            if (st) *reinterpret_cast<u32x4 *>(o + a.out_lo_off) = u32x4{d[0], d[1], d[2], 0u};
+                        } else
                         if (st) *reinterpret_cast<u32x4 *>(o + a.out_lo_off) = u32x4{l0[0], l0[1], l1[0], l1[1]};
                     }
                 }

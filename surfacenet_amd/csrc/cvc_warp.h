@@ -89,7 +89,7 @@ static __global__ void __launch_bounds__(256) cvc_warp_kernel(CvcArgs a)
         y[6] = y[7] = 0.f;
         _Float16 *o = a.out_x0 + ((size_t)sample * s3 + vox) * 8;
         if (a.x0_mode == 1) sn_store8<1>(o, a.x0_lo_off, y);
-        else if (a.x0_mode == 2) sn_store8<2>(o, a.x0_lo_off, y);
+        else if (a.x0_mode == 2) sn_store8<2>(o, a.x0_lo_off, y, kMxX0E8);
         else sn_store8<0>(o, 0, y);
     }
 }
@@ -107,7 +107,7 @@ static __global__ void __launch_bounds__(256) ncdhw_to_x0_kernel(const float *X,
     y[6] = y[7] = 0.f;
     _Float16 *o = x0 + ((size_t)sample * s3 + vox) * 8;
     if (x0_mode == 1) sn_store8<1>(o, x0_lo_off, y);
-    else if (x0_mode == 2) sn_store8<2>(o, x0_lo_off, y);
+    else if (x0_mode == 2) sn_store8<2>(o, x0_lo_off, y, kMxX0E8);
     else sn_store8<0>(o, 0, y);
 }
 

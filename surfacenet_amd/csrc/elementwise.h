@@ -12,12 +12,13 @@
 
 namespace sn {
 
+#include "mx_format.h"
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // One 8-channel group of an activation tensor <-> 8 fp32 values, for the three storage modes of conv3d_mfma.h:
-//   SPLIT 0: fp16;  SPLIT 1: hi + lo fp16 planes;  SPLIT 2: fp16 hi plane + 16-byte slot [fp8(hi) x8 | fp8(lo*2^12) x8].
+//   SPLIT 0: fp16;  SPLIT 1: hi + lo fp16 planes;  SPLIT 2: fp16 hi plane + 16-byte slot of low-precision codes (mx_format.h).
 template <int SPLIT>
-__device__ __forceinline__ void sn_load8(const _Float16 *p, long long lo_off, float (&v)[8])
+__device__ __forceinline__ void sn_load8(const _Float16 *p, long long lo_off, float (&v)[8], int e8 = kMxActE8)
 {
     const h8 q = *reinterpret_cast<const h8 *>(p);
     if constexpr (SPLIT == 0) {
@@ -29,11 +30,19 @@ __device__ __forceinline__ void sn_load8(const _Float16 *p, long long lo_off, fl
         for (int e = 0; e < 8; ++e) v[e] = (float)q[e] + (float)ql[e];
     } else {
         const uint4 s = *reinterpret_cast<const uint4 *>(p + lo_off);
-        const float sc = 1.0f / 4096.0f;
+#if SN_MX_FMT == 0
+        const float sc = 1.0f / kMxLoMul;
         v[0] = (float)q[0] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 0) * sc; v[1] = (float)q[1] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 1) * sc;
         v[2] = (float)q[2] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 2) * sc; v[3] = (float)q[3] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 3) * sc;
         v[4] = (float)q[4] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 0) * sc; v[5] = (float)q[5] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 1) * sc;
         v[6] = (float)q[6] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 2) * sc; v[7] = (float)q[7] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 3) * sc;
+#else
+        // codes [hi c0..3 | lo c0..3 | hi c4..7 | lo c4..7] of (value * 2^(127 - e8)); lo additionally * 2^kMxLoExp
+        const mx_v32f d = sn_mx6_decode(mx_v6i{(int)s.x, (int)s.y, (int)s.z, 0, 0, 0});
+        const float sc = sn_e8_to_float(e8) / kMxLoMul;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (float)q[e] + d[4 + e] * sc; v[4 + e] = (float)q[4 + e] + d[12 + e] * sc; }
+#endif
     }
 }
 __device__ __forceinline__ int sn_fp8x4(float a, float b, float c, float d)
@@ -43,7 +52,7 @@ __device__ __forceinline__ int sn_fp8x4(float a, float b, float c, float d)
     return __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
 }
 template <int SPLIT>
-__device__ __forceinline__ void sn_store8(_Float16 *p, long long lo_off, const float (&v)[8])
+__device__ __forceinline__ void sn_store8(_Float16 *p, long long lo_off, const float (&v)[8], int e8 = kMxActE8)
 {
     h8 h;
     float lo[8];
@@ -60,10 +69,21 @@ __device__ __forceinline__ void sn_store8(_Float16 *p, long long lo_off, const f
         *reinterpret_cast<h8 *>(p + lo_off) = l;
     } else if constexpr (SPLIT == 2) {
         uint4 s;
+#if SN_MX_FMT == 0
         s.x = (unsigned)sn_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
         s.y = (unsigned)sn_fp8x4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
-        s.z = (unsigned)sn_fp8x4(lo[0] * 4096.f, lo[1] * 4096.f, lo[2] * 4096.f, lo[3] * 4096.f);
-        s.w = (unsigned)sn_fp8x4(lo[4] * 4096.f, lo[5] * 4096.f, lo[6] * 4096.f, lo[7] * 4096.f);
+        s.z = (unsigned)sn_fp8x4(lo[0] * kMxLoMul, lo[1] * kMxLoMul, lo[2] * kMxLoMul, lo[3] * kMxLoMul);
+        s.w = (unsigned)sn_fp8x4(lo[4] * kMxLoMul, lo[5] * kMxLoMul, lo[6] * kMxLoMul, lo[7] * kMxLoMul);
+#else
+        mx_v32h t = {};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t[e] = h[e]; t[4 + e] = (_Float16)(lo[e] * kMxLoMul);
+            t[8 + e] = h[4 + e]; t[12 + e] = (_Float16)(lo[4 + e] * kMxLoMul);
+        }
+        const mx_v6i c = sn_mx6_cvt(t, e8);
+        s.x = (unsigned)c[0]; s.y = (unsigned)c[1]; s.z = (unsigned)c[2]; s.w = 0u;
+#endif
         *reinterpret_cast<uint4 *>(p + lo_off) = s;
     }
 }
@@ -121,7 +141,7 @@ __device__ __forceinline__ void up_axis(int o, int n_in, int &m, float &wa, floa
 template <int SPLIT, int OSPLIT = SPLIT>
 __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, const _Float16 *s3, const _Float16 *s4, _Float16 *cat,
                                                             int Do, int cat_cs, long long total, long long lo2, long long lo3,
-                                                            long long lo4, long long out_lo_off)
+                                                            long long lo4, long long out_lo_off, int out_e8)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -155,7 +175,7 @@ __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, 
         }
     }
     _Float16 *o = cat + ((((b * (cat_cs >> 3) + 2 + g) * Do + x) * Do + y) * Do + z) * 8LL;
-    sn_store8<OSPLIT>(o, out_lo_off, acc);   // OSPLIT: storage format the consumer (merge_conv_a) computes in
+    sn_store8<OSPLIT>(o, out_lo_off, acc, out_e8);   // OSPLIT: storage format the consumer (merge_conv_a) computes in
 }
 
 // unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.

@@ -47,6 +47,28 @@ static unsigned char fp8_e4m3(float v)
     return sgn | (unsigned char)(be << 3) | (unsigned char)mant;
 }
 
+// 6-bit minifloat encoder for the MX forms (mx_format.h): fmt 2 = fp6 e2m3 (bias 1, max 7.5), fmt 3 = bf6 e3m2 (bias 3, max 28);
+// round-to-nearest-even, saturating, with subnormals (decoder: tools/probe/fp6_probe.hip dec6()).
+static unsigned char mx6_encode(float v, int fmt)
+{
+    const int mb = fmt == 2 ? 3 : 2, bias = fmt == 2 ? 1 : 3, emax = fmt == 2 ? 3 : 7;
+    const float vmax = std::ldexp((float)((2 << mb) - 1), emax - bias - mb);
+    if (v != v) return 0;
+    const unsigned char sgn = std::signbit(v) ? 0x20 : 0;
+    float a = std::min(std::fabs(v), vmax);
+    int e;
+    std::frexp(a, &e);
+    int E = (a > 0.f) ? e - 1 : 1 - bias;                    // a = (1 + f) * 2^E
+    if (E < 1 - bias) E = 1 - bias;                          // subnormal range: the exponent of the smallest normal binade
+    int mant = (int)std::nearbyint(std::ldexp(a, mb - E));   // in units of 2^(E-mb): [2^mb, 2^(mb+1)) normal, below 2^mb subnormal
+    int be = E + bias;
+    if (mant < (1 << mb)) be = 0;
+    else { if (mant == (2 << mb)) { mant = 1 << mb; be += 1; } mant -= 1 << mb; }
+    if (be > emax) { be = emax; mant = (1 << mb) - 1; }
+    return sgn | (unsigned char)(be << mb) | (unsigned char)mant;
+}
+static float mx6_max(int fmt) { return fmt == 2 ? 7.5f : 28.f; }
+
 // W is given as (cout, cin, k,k,k) row-major fp32 (dilated layers are transposed by the caller).
 // Packed layouts (one stream per cout split, slabs back to back):
 //   split 0 (f16)  : [slab][chunk][nf]{ hi fragment: 64 lanes x 8 halfs }
@@ -150,6 +172,49 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, co
                         for (int lane = 0; lane < 64; ++lane) {
                             const int o = (ns * nf + f) * 16 + (lane & 15), q = lane >> 4;
                             unsigned char *frag = mx + (size_t)f * 2048;   // two lane-linear 1 KiB halves: k bytes 0-15 | 16-31
+                            if (SN_MX_FMT != 0) {
+                                // 6-bit forms: lane quarter q covers groups 8p+2q (elements 0..15 of its 32-element block) and 8p+2q+1 (16..31), one
+                                // E8M0 scale per block. Code position within a group follows the
+                                // activation slot [x_hi c0..3 | x_lo c0..3 | x_hi c4..7 | x_lo c4..7] with the OTHER part of the weight: w_lo * 2^L
+                                // against x_hi, w_hi against x_lo * 2^L; the common 2^-L and the block exponent go into the scale.
+                                float val[32];
+                                float amax = 0.f;
+                                for (int i = 0; i < 2; ++i) {
+                                    const int g = 8 * p + 2 * q + i;
+                                    for (int pos = 0; pos < 16; ++pos) {
+                                        const int j = (pos & 3) + 4 * (pos >> 3);
+                                        const bool lo_part = !(pos & 4);
+                                        float t = 0.f;
+                                        if (g < G) {
+                                            const float w = wat(o, c8_0 + g % c8n, j, g / c8n);
+                                            const float hi = (float)(_Float16)w;
+                                            t = lo_part ? (w - hi) * kMxLoMul : hi;
+                                        }
+                                        val[i * 16 + pos] = t;
+                                        amax = std::max(amax, std::fabs(t));
+                                    }
+                                }
+                                int E = 0;
+                                if (amax > 0.f) {
+                                    E = std::ilogb(amax / mx6_max(SN_MX_FMT));
+                                    if (std::ldexp(amax, -E) > mx6_max(SN_MX_FMT)) ++E;
+                                }
+                                E = std::max(-100, std::min(100, E));
+                                unsigned w6[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+                                for (int el = 0; el < 32; ++el) {
+                                    const unsigned code = mx6_encode(std::ldexp(val[el], -E), SN_MX_FMT);
+                                    const int bit = 6 * el;
+                                    w6[bit >> 5] |= code << (bit & 31);
+                                    if ((bit & 31) > 26) w6[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                                }
+                                // operand dwords 0..3 in the first lane-linear KiB, dwords 4..5 in the second (a 128-bit and a 64-bit read)
+                                unsigned *d0 = reinterpret_cast<unsigned *>(frag + lane * 16), *d1 = reinterpret_cast<unsigned *>(frag + 1024 + lane * 16);
+                                d0[0] = w6[0]; d0[1] = w6[1]; d0[2] = w6[2]; d0[3] = w6[3];
+                                d1[0] = w6[4]; d1[1] = w6[5];
+                                // block scales of the lane's nf fragments: bytes 8.. of its 16 bytes in the second KiB of fragment 0
+                                (mx + 1024 + lane * 16 + 8)[f] = (unsigned char)std::max(0, std::min(254, 127 + E - kMxLoExp));
+                                continue;
+                            }
                             for (int i = 0; i < 4; ++i) {
                                 // SN_MX_B128: lane quarter q covers groups 8p+2q, 8p+2q+1, 8-byte sections [w_lo | w_hi | w_lo | w_hi] (the
                                 // activation slots read [x_hi | x_lo]); else: q<2 -> w_lo, q>=2 -> w_hi of the 4 groups 8p + 4(q&1) + i
@@ -160,7 +225,7 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, co
                                     const float w = wat(o, c8_0 + g % c8n, j, g / c8n);
                                     const float hi = (float)(_Float16)w;
                                     const int kb = i * 8 + j;
-                                    frag[(kb >> 4) * 1024 + lane * 16 + (kb & 15)] = lo_part ? fp8_e4m3((w - hi) * 4096.f) : fp8_e4m3(hi);
+                                    frag[(kb >> 4) * 1024 + lane * 16 + (kb & 15)] = lo_part ? fp8_e4m3((w - hi) * kMxLoMul) : fp8_e4m3(hi);
                                 }
                             }
                         }
@@ -243,7 +308,7 @@ static int launch_up3(sn_ctx *c, Act s2, Act s3, Act s4, Act cat, int B, int Do,
     const long long total = (long long)B * Do * Do * Do * 6;
     ProfScope ps(c, "side_op234_deconv", 0, (double)B * Do * Do * Do * 48 * 2.0 * (SPLIT ? 2 : 1));
     hipLaunchKernelGGL((upsample3_cat_kernel<SPLIT, OSPLIT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, s2.p, s3.p, s4.p,
-                       cat.p, Do, cat_cs, total, s2.lo, s3.lo, s4.lo, cat.lo);
+                       cat.p, Do, cat_cs, total, s2.lo, s3.lo, s4.lo, cat.lo, c->mx_cat_e8);
     HIPCHK(hipGetLastError());
     return SN_OK;
 }
@@ -465,6 +530,11 @@ int sn_set_precision(sn_ctx *c, int mode)
     c->split = mode == SN_PRECISION_F16X3_PURE ? 1 : mode;
     c->tail_m8 = mode == SN_PRECISION_F16X3 ? 2 : 0;
     if (mode == SN_PRECISION_F16X3 && getenv("SN_M8_TAIL")) c->tail_m8 = std::max(0, std::min(2, atoi(getenv("SN_M8_TAIL"))));   // A/B measurements only
+    c->mx_act_e8 = kMxActE8; c->mx_cat_e8 = kMxCatE8;
+    if (mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0) {                                       // accuracy sweeps only (mx_format.h)
+        if (getenv("SN_MX_S_ACT")) c->mx_act_e8 = 127 - std::max(-8, std::min(8, atoi(getenv("SN_MX_S_ACT"))));
+        if (getenv("SN_MX_S_CAT")) c->mx_cat_e8 = 127 - std::max(-8, std::min(8, atoi(getenv("SN_MX_S_CAT"))));
+    }
     return SN_OK;
 }
 

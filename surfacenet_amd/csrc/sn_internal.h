@@ -80,6 +80,7 @@ struct sn_ctx {
     bool have_weights = false, have_relw = false;
     int split = 1;              // 0: f16 operands; 1: f16x3 (hi/lo split operands, fp32-class results) — default; 2: f16m8
     int mode = 1;               // the SN_PRECISION_* value given to sn_set_precision
+    int mx_act_e8 = kMxActE8, mx_cat_e8 = kMxCatE8;   // mx_format.h; SN_MX_S_ACT / SN_MX_S_CAT in the environment override them in the default (hybrid) mode
     int tail_m8 = 2;            // f16x3: how many of the last 3x3x3 layers run their two correction terms on the MX-fp8 MFMA
                                 // (0 none = f16x3p, 1 merge_conv_b, 2 merge_conv_a + merge_conv_b); env SN_M8_TAIL overrides (A/B runs)
     bool ws_ready = false; int ws_split = -1;
@@ -242,6 +243,11 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
             return fail(SN_ERR_ARG, "%s: %d images of %dx%d exceed the 256 MiB this kernel's halo addressing covers per channel slab", L.name.c_str(), DX, D, D);
     }
     a.act = L.act;
+    {
+        // static premultipliers of the 6-bit code planes (mx_format.h): the concat buffer holds sigmoid outputs, everything else ReLU(BN(.))
+        auto e8_of = [&](const _Float16 *t) { return t && t == c->cat ? c->mx_cat_e8 : (t && t == c->x0 ? kMxX0E8 : c->mx_act_e8); };
+        a.mx_in_e8 = e8_of(in.p); a.mx_out_e8 = e8_of(out.p); a.mx_side_e8 = sf ? e8_of(sf->side_out.p) : c->mx_act_e8;
+    }
     if (EPI == EPI_SIDEPOOL) {
         if (!sf || !sf->side || !sf->side->side_frag || sf->side->cin != L.cout || sf->side->cout != 16 || L.nsplit != 1 || L.act != 0 || (D & 1))
             return fail(SN_ERR_STATE, "%s: fused side-conv / pool epilogue misconfigured", L.name.c_str());

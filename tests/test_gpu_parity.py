@@ -58,9 +58,14 @@ def test_cvc_bad_view_index(sn):
 #   summation order flips half-ulp fp16 roundings of stored activations)
 TOL_X3, TOL_F16_EMU, TOL_F16 = 2e-4, 5e-3, 1e-2
 TOL_X3P = 5e-5
-#   f16m8 (f16 main term + MX-fp8 correction terms): vs fp64 < 5e-4 (observed ~1e-4; north-star bar 1e-3); vs the oracle
-#   that emulates its storage/operand formats < 2e-4
-TOL_M8, TOL_M8_EMU = 5e-4, 2e-4
+#   vs oracle/net_emulation.py, the CPU model of the device arithmetic of the default mode (renormalisation exponents, hi/lo storage, 6-bit
+#   MX codes and block scales of the merge layers): the model must explain most of the device's deviation from fp64 — max difference
+#   observed 2e-5 .. 5e-5, rms difference 0.5 .. 0.6 of the device's rms error (the rest: fp32 accumulation inside the MFMAs, which is not
+#   one correctly rounded addition per instruction - tools/probe/fp6_probe.hip measures up to 1.6 ulp - and 6-bit code flips it causes)
+TOL_X3_EMU, RMS_X3_EMU = 1e-4, 0.8
+#   f16m8 (every layer: f16 main term + 6-bit MX correction terms; experimental, dominated by the default in speed and accuracy):
+#   vs fp64 within the north-star bar (observed 6e-5 .. 4e-4); vs its CPU model (which simplifies the fused side convolutions) < 2e-4
+TOL_M8, TOL_M8_EMU = 1e-3, 2e-4
 
 
 def _net_case(s, n, n_vp, seed):
@@ -84,14 +89,20 @@ def test_forward_vs_oracle(sn, s, n, n_vp, precision):
     assert u64.std() > 0.05 and u64.min() < 0.2 and u64.max() > 0.8          # the test net is not degenerate
     e_ref, e_fused = np.abs(unfused - u64).max(), np.abs(fused - f64).max()
     print("%s s=%d: L_inf vs fp64 oracle: unfused %.3e fused %.3e" % (precision, s, e_ref, e_fused))
-    if precision == "f16x3":         # default: f16x3 with the merge layers' correction terms on the MX-fp8 MFMA (observed 3e-5 .. 7e-5)
-        assert e_ref < TOL_X3 and e_fused < TOL_X3
+    if precision == "f16x3":         # default: f16x3 with the merge layers' correction terms on the 6-bit MX MFMA (observed 3e-5 .. 1e-4)
+        from oracle import net_emulation
+        fe, ue = net_emulation.forward_emulated(X, values, w=w, n_vp=n_vp, mode="f16x3")
+        e_emu, r_emu, r_ref = np.abs(unfused - ue).max(), np.sqrt(np.mean((unfused - ue) ** 2)), np.sqrt(np.mean((unfused - u64) ** 2))
+        print("   vs the CPU model of the device arithmetic: max %.3e rms %.3e (device vs fp64: rms %.3e; the model itself vs fp64: max %.3e)"
+              % (e_emu, r_emu, r_ref, np.abs(ue - u64).max()))
+        assert e_ref < TOL_X3 and e_fused < TOL_X3 and e_emu < TOL_X3_EMU and r_emu < RMS_X3_EMU * r_ref
     elif precision == "f16x3p":      # every layer on three fp16 MFMAs (observed ~1e-5)
         assert e_ref < TOL_X3P and e_fused < TOL_X3P
     elif precision == "f16m8":
-        fm, um = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp, quant="f16m8")
+        from oracle import net_emulation
+        fm, um = net_emulation.forward_emulated(X, values, w=w, n_vp=n_vp, mode="f16m8")
         e_emu = np.abs(unfused - um).max()
-        print("   vs f16m8-emulating oracle %.3e (emulation itself vs fp64: %.3e)" % (e_emu, np.abs(um - u64).max()))
+        print("   vs the CPU model of the device arithmetic %.3e (the model itself vs fp64: %.3e)" % (e_emu, np.abs(um - u64).max()))
         assert e_ref < TOL_M8 and e_fused < TOL_M8 and e_emu < TOL_M8_EMU
     else:
         f16, u16 = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp, quant="fp16")
@@ -371,5 +382,5 @@ def test_epilogue_fusion_equals_separate_launches(gpu_required, tmp_path):
     for k in outs[0].files:
         a, b = outs[0][k], outs[1][k]
         # f16x3: fp32-class; f16m8: the stand-alone side kernel computes in f16m8, the fused one on three fp16 MFMAs; f16: fp16-class
-        tol = 2e-3 if "_f16_" in k else (2e-4 if "_f16m8_" in k else 2e-5)
+        tol = 2e-3 if "_f16_" in k else (1e-3 if "_f16m8_" in k else 2e-5)
         assert a.shape == b.shape and np.abs(a - b).max() < tol, (k, float(np.abs(a - b).max()))

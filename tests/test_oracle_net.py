@@ -72,3 +72,19 @@ def test_relative_weights_softmax():
     f = np.random.RandomState(4).rand(6, 258).astype(np.float32)
     sm = no.relative_weights(f, vals, 3)
     assert sm.shape == (2, 3) and np.allclose(sm.sum(axis=1), 1.0) and (sm > 0).all()
+
+
+def test_device_arithmetic_model_stays_close_to_the_oracle():
+    """oracle/net_emulation.py (the CPU model of the HIP path's roundings, used by the GPU parity tests as a second, tighter reference):
+    on a BN-calibrated net it must sit where the design says — far inside the 1e-3 bar, the all-MX mode behind the default."""
+    import synth
+    from oracle import net_emulation
+    values = list(synth.calibrated_params(2))
+    X = synth.random_cvc(2, 8, 18)
+    f64, u64 = no.forward_torch(X, values, n_vp=1)
+    e = {}
+    for mode in ("f16x3", "f16m8"):
+        fe, ue = net_emulation.forward_emulated(X, values, n_vp=1, mode=mode)
+        assert ue.shape == u64.shape
+        e[mode] = np.abs(ue - u64).max()
+    assert 1e-7 < e["f16x3"] < 1e-4 and e["f16x3"] < e["f16m8"] < 5e-4, e
