@@ -58,17 +58,19 @@ int sn_synchronize(sn_ctx *ctx);
 
 /* Arithmetic of the 3D-CNN (the CVC warp is always the reference's fp64/int arithmetic):
  *   SN_PRECISION_F16X3 (default): operands carried as hi+lo pairs of fp16 (22 significant bits), three
- *       MFMAs per product term, fp32 accumulate -> fp32-class results (L_inf vs fp64 oracle ~2e-5). The LAST 3x3x3
- *       layer (merge_conv_b, the dominant kernel) computes its two correction terms on one MX-fp8 MFMA (as
- *       SN_PRECISION_F16M8 does everywhere): -14 % on that kernel for ~1e-5 of L_inf;
+ *       MFMAs per product term, fp32 accumulate -> fp32-class results. The two LAST 3x3x3 layers (merge_conv_a,
+ *       merge_conv_b: 56 % of a step) compute their two correction terms on one MX-scaled MFMA with 6-bit
+ *       (fp6 e2m3) operands, which issues at twice the fp16 rate: 1.5 MFMA units per product instead of 3.
+ *       L_inf vs the fp64 oracle 3e-5 .. 1e-4 (bar 1e-3);
  *   SN_PRECISION_F16X3_PURE: all three MFMAs in fp16 in every layer (L_inf ~1e-5);
  *   SN_PRECISION_F16: operands rounded to fp16, fp32 accumulate -> 3x faster, L_inf ~2e-3 on BN-normalised
  *       nets, i.e. above the 1e-3 parity bar; opt-in fast mode.
  * Call before sn_load_weights (weights are packed for the selected mode). */
 #define SN_PRECISION_F16 0
 #define SN_PRECISION_F16X3 1
-/*   SN_PRECISION_F16M8: main term on the f16 MFMA, the two 2^-11 correction terms on one MX-scaled fp8 MFMA
- *       (v_mfma_scale_f32_16x16x128_f8f6f4): 2 MFMA units per product; L_inf ~1e-4 (bar 1e-3). */
+/*   SN_PRECISION_F16M8 (experimental; the default dominates it in speed and accuracy): EVERY layer with the main term
+ *       on the f16 MFMA and the two 2^-11 correction terms on one MX-scaled 6-bit MFMA
+ *       (v_mfma_scale_f32_16x16x128_f8f6f4); L_inf 1e-4 .. 4e-4 (bar 1e-3). */
 #define SN_PRECISION_F16M8 2
 #define SN_PRECISION_F16X3_PURE 3
 int sn_set_precision(sn_ctx *ctx, int mode);

@@ -9,7 +9,7 @@ MEAN_CVC_RGBRGB = np.asarray([123.68, 116.779, 103.939, 123.68, 116.779, 103.939
 
 
 class Context(object):
-    PRECISIONS = {"f16": 0, "f16x3": 1, "f16m8": 2, "f16x3p": 3}      # f16x3p: f16x3 without the fp8 tail (see surfacenet_hip.h)
+    PRECISIONS = {"f16": 0, "f16x3": 1, "f16m8": 2, "f16x3p": 3}      # f16x3p: f16x3 without the MX tail (see surfacenet_hip.h)
 
     def __init__(self, cube_D=32, max_samples=64, device=0, precision="f16x3"):
         """precision: "f16x3" (default; fp32-class results, operands as hi+lo fp16 pairs, 3 MFMAs per term) or
