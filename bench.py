@@ -36,7 +36,7 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.m
 CNN_FLOPS_PER_SAMPLE_S32 = 44511690752   # learned-conv FLOPs per cube-view-pair at s=32
 
 
-KERNEL_SOURCES = ["conv3d_mfma.h", "cvc_warp.h", "elementwise.h", "sn_internal.h", "sn_api.hip"]
+KERNEL_SOURCES = ["conv3d_mfma.h", "mx_format.h", "cvc_warp.h", "elementwise.h", "sn_internal.h", "sn_api.hip"]
 
 
 def kernel_src_sha16():
