@@ -60,6 +60,9 @@
 #ifndef SN_STATIC_PRIO
 #define SN_STATIC_PRIO 1   // +0.7 % on the 3-D f16x3 / f16m8 kernels (merge_conv_b -1.6 %); -0.8 % in f16 mode and on the 2-D kernels -> off there
 #endif
+#ifndef SN_ESPREAD
+#define SN_ESPREAD 1
+#endif
 #ifndef SN_MX_B128
 #define SN_MX_B128 1     // f16m8 MX step: a lane covers BOTH correction terms of 2 channel groups (two 16-byte slot reads) instead of ONE term of 4 groups
 #endif                   // (four 8-byte reads): half the activation-fetch instructions of the step, 2 tap offsets instead of 4; the weight packing follows (pack_conv)
@@ -81,7 +84,8 @@
 #define SN_DMA_LATE 0     // issue the piece's DMAs behind its first MFMA group instead of in front of it: measured null (r2x: +-0.3 %, 30-step A/B)
 #endif
 #ifndef SN_TIMING
-#define SN_TIMING 0       // diagnostic build: per-wave shader-clock totals (whole kernel, vmcnt wait, barrier wait) added into a.status[1..] (results stay valid)
+#define SN_TIMING 0       // diagnostic build: per-wave shader-clock totals (whole kernel, vmcnt wait, barrier wait) added into a.status[1..] (results stay valid);
+                          // 3..6 (f16m8 kernels): the two wait slots hold segment times of a weight piece instead, see the piece loop
 #endif
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
@@ -187,6 +191,8 @@ __device__ __forceinline__ void sn_mx6_store_unit(char *slot, int half, const _F
     unsigned short *d = reinterpret_cast<unsigned short *>(slot) + 3 * half;
     d[0] = (unsigned short)w[0][0]; d[1] = (unsigned short)(w[0][0] >> 16); d[2] = (unsigned short)w[0][1];
 }
+// E reads (tap offset, next chunk's activation fragments, MX operands) issued behind group g of a chunk when ET reads are spread PER per group
+constexpr int sn_e_after(int g, int ET, int PER) { return g < 0 ? 0 : (g * PER >= ET ? 0 : ((g + 1) * PER <= ET ? PER : ET - g * PER)); }
 // fp8 e4m3 pack of four fp32 values (round-to-nearest-even, saturating at +-448)
 __device__ __forceinline__ int sn_pack_fp8x4(float a, float b, float c, float d)
 {
@@ -508,7 +514,7 @@ conv3d_f16_mfma(ConvArgs a)
 #endif
     int xb = 0;     // halo / tap-table buffer holding the current slab
     int wbi = 0;    // weight buffer holding the current piece
-    long long t_vm = 0, t_bar = 0, n_piece = 0;
+    long long t_vm = 0, t_bar = 0, n_piece = 0, t_mx = 0, t_rel = 0, t_c0 = 0, t_dma = 0;
     const long long t_kernel0 = SN_TIMING ? __builtin_readcyclecounter() : 0;
     bool bad = false;   // a stored value left the fp16 range / is NaN (checked on the fp32 value in the epilogue)
     constexpr float kF16Max = 65504.f;
@@ -639,6 +645,7 @@ conv3d_f16_mfma(ConvArgs a)
                     }
                 };
                 if constexpr (!SN_DMA_LATE) issue_dmas();
+                if constexpr (SN_TIMING >= 7) { t_dma = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                 static_for<0, C::PCH>([&](auto ccc) {
                     constexpr int cc = decltype(ccc)::value;
                     const int ch = ch0 + cc;
@@ -652,19 +659,25 @@ conv3d_f16_mfma(ConvArgs a)
                             // reads issued after this group's fragment and allowed to stay in flight while it is waited for: the fragments of the next
                             // WD groups, plus (E) the tap offset / activation fragments [/ MX operands] that group 0 of the chunk issues behind its MFMAs
                             constexpr int E = 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? (SN_MX_B128 ? 2 : 4) * MF + 1 : 0);
+                            // SPR: the E reads are not issued in one burst behind group 0 but PER at a time behind groups 0 .. NF-1-WD. A burst of 14 reads
+                            // per wave (8 waves at once, right after the barrier) filled the LDS queue, and the weight fragment of group WD+1 - issued
+                            // behind the burst, returned in order - made chunk 0 take 1,640 clocks for 450 of MFMA issue (wave timing, SN_TIMING 5)
+                            constexpr bool SPR = SN_ESPREAD && SPLIT == 2 && SN_MX_B128 && NF - WD >= 2;   // (f16x3 / f16 kernels: conv2_x +2 %, the rest unchanged -> burst kept)
+                            constexpr int PER = SPR ? (E + NF - WD - 1) / (NF - WD) : E;
+                            constexpr int EQ = sn_e_after(n - 1, E, PER) + (WD == 2 ? sn_e_after(n - 2, E, PER) : 0);   // E reads younger than the awaited fragment
                             if constexpr (WD == 2) {
                                 if constexpr (G + 2 < GT && !(SN_ABL & 16)) {
                                     lds_read128<(G + 2) * C::MFRAG>(wr[nxt][0], wp);
                                     if constexpr (SPLIT == 1) lds_read128<(G + 2) * C::MFRAG + 1024>(wr[nxt][1], wp);
                                 }
-                                lgkm_wait<NPLM * ((G + 1 < GT ? 1 : 0) + (G + 2 < GT ? 1 : 0)) + ((n == 1 || n == 2) ? E : 0)>();
+                                lgkm_wait<NPLM * ((G + 1 < GT ? 1 : 0) + (G + 2 < GT ? 1 : 0)) + EQ>();
                             } else {
                                 constexpr int wo = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::MFRAG;
                                 if constexpr ((more_n || more_c) && !(SN_ABL & 16)) {
                                     lds_read128<wo>(wr[nxt][0], wp);
                                     if constexpr (SPLIT == 1) lds_read128<wo + 1024>(wr[nxt][1], wp);
                                 }
-                                lgkm_wait<((more_n || more_c) ? NPLM : 0) + (n == 1 ? E : 0)>();
+                                lgkm_wait<((more_n || more_c) ? NPLM : 0) + EQ>();
                             }
                             if constexpr (!(SN_ABL & 4)) {
                                 if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -684,6 +697,31 @@ conv3d_f16_mfma(ConvArgs a)
                                 asm volatile("" ::"v"(wr[cur][0]), "v"(xc[0][0]));
                             }
                             if constexpr (SN_DMA_LATE && cc == 0 && n == 0) issue_dmas();
+                            if constexpr (SPR) {
+                                constexpr int NX = MF * NPLM;
+                                static_for<0, E>([&](auto rc) {
+                                    constexpr int r = decltype(rc)::value;
+                                    if constexpr (r / PER == n) {
+                                        if constexpr (r == 0) {
+                                            lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
+                                        } else if constexpr (r <= NX) {
+                                            constexpr int m = (r - 1) / NPLM, pl = (r - 1) % NPLM;
+                                            const unsigned ad = xaddr[m] + (unsigned)ko1;
+                                            if constexpr (SN_ABL & 32) {
+                                            } else if constexpr (pl == 0) lds_read128<0>(xn[0][m], ad);
+                                            else if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(xn[1][m], ad);
+                                            else lds_read128<0>(xn[1][m], ad + C::XPLANE);
+                                        } else if constexpr (r <= NX + 2 * MF) {
+                                            constexpr int m = (r - NX - 1) / 2, sl = (r - NX - 1) % 2;
+                                            const unsigned ad = xaddr[m] + C::XPLANE + (unsigned)(int)(sl ? (k2 >> 32) : k2);
+                                            if constexpr (SN_MX_FMT != 0) lds_read96i<0>(x6[m][sl], ad);   // the 12 code bytes of a slot = half of the lane's 192-bit operand
+                                            else lds_read128i<0>(x8h[m][sl], ad);                         // whole 16-byte slot [fp8(hi) x8 | fp8(lo*2^12) x8]
+                                        } else {
+                                            lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);       // tap offsets of the next piece's MX step
+                                        }
+                                    }
+                                });
+                            } else
                             if constexpr (n == 0) {
                                 lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
                                 issue_x(xn, ko1);
@@ -726,6 +764,7 @@ conv3d_f16_mfma(ConvArgs a)
                         }
                         ko1 = ko2;
                     }
+                    if constexpr (SN_TIMING >= 5 && cc == 0) { t_c0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                     if constexpr (SPLIT == 2 && cc == 0 && !(SN_ABL & 256)) {
                         // MX step (placed between the piece's two f16 chunks so the fp8 operands are short-lived): both correction
                         // terms of this piece's 64 k in one fp8 MFMA per (cout, voxel) fragment pair;
@@ -796,6 +835,7 @@ conv3d_f16_mfma(ConvArgs a)
                             }
                         });
                         }
+                        if constexpr (SN_TIMING >= 3) { t_mx = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                     }
                 });
                 lgkm_wait<0>();
@@ -810,7 +850,16 @@ conv3d_f16_mfma(ConvArgs a)
                     if constexpr (SN_TIMING) {
                         const long long tq2 = __builtin_readcyclecounter();
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        t_vm += tq1 - tq0; t_bar += tq2 - tq1;
+                        if constexpr (SN_TIMING >= 7) {       // 7 / 8: [1] += piece start -> weight DMAs issued (and the first fragments landed), [2] += the rest of chunk 0
+                            if ((SN_TIMING == 7) == (wave >= C::NW / 2) && t_rel != 0 && p != 0) { t_vm += t_dma - t_rel; t_bar += t_c0 - t_dma; }
+                            t_rel = tq2;
+                        } else if constexpr (SN_TIMING >= 5) {       // 5 / 6 (waves >= NW/2 / < NW/2): [1] += piece start -> end of chunk 0, [2] += end of chunk 0 -> MX step done
+                            if ((SN_TIMING == 5) == (wave >= C::NW / 2) && t_rel != 0 && p != 0) { t_vm += t_c0 - t_rel; t_bar += t_mx - t_c0; }
+                            t_rel = tq2;
+                        } else if constexpr (SN_TIMING >= 3) { // 3 / 4: [1] += piece start -> MX step done, [2] += MX step done -> end of chunk 1 (pieces p > 0 of a slab)
+                            if ((SN_TIMING == 3) == (wave >= C::NW / 2) && t_rel != 0 && p != 0) { t_vm += t_mx - t_rel; t_bar += tq0 - t_mx; }
+                            t_rel = tq2;
+                        } else { t_vm += tq1 - tq0; t_bar += tq2 - tq1; }
                         if (EPI == EPI_FINAL && a.status && blockIdx.x == 0 && n_piece < 2048 && lane == 0) {     // trace of workgroup 0: [piece][wave]{arrive, release}
                             long long *tr = reinterpret_cast<long long *>(a.status + 2 + 32 * 8) + ((size_t)n_piece * C::NW + wave) * 2;
                             tr[0] = tq1; tr[1] = tq2;

@@ -378,7 +378,11 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     if constexpr (SP == 1) {
         if (c->tail_m8 >= 2) {
             RUN((launch_conv<3, 1, 4, 7, EPI_STORE, 2, 1, 2, 8, 0>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
+#ifdef SN_MB_WIDE
+            RUN((launch_conv<3, 1, 8, 7, EPI_FINAL, 2, 1, 2, 4, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
+#else
             RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
+#endif
             return SN_OK;
         }
         if (c->tail_m8 == 1) {
