@@ -60,6 +60,9 @@
 #ifndef SN_STATIC_PRIO
 #define SN_STATIC_PRIO 1   // +0.7 % on the 3-D f16x3 / f16m8 kernels (merge_conv_b -1.6 %); -0.8 % in f16 mode and on the 2-D kernels -> off there
 #endif
+#ifndef SN_DEFER
+#define SN_DEFER 1
+#endif
 #ifndef SN_ESPREAD
 #define SN_ESPREAD 1
 #endif
@@ -576,7 +579,14 @@ conv3d_f16_mfma(ConvArgs a)
             // distance 2 pays only where it costs no spills and the MFMA groups are short (r2y: merge_conv_b -1.4 %, merge_conv_a 0, conv4 +10 %)
             constexpr int WD = (SN_WDIST == 2 && EPI == EPI_FINAL && SPLIT == 2) ? 2 : 1;
             static_assert(WD == 1 || WD == 2, "weight prefetch distance");
-            half8 xc[NPLM][MF], xn[NPLM][MF], wr[WD + 1][NPLM];
+            // DEFER (f16m8 kernels: pieces are always full): the per-piece barrier sits in front of the LAST TWO MFMA groups of a piece instead of
+            // behind them. Their weight fragments are already in registers (wsp), so after the barrier the wave first requests the next
+            // piece's fragments and issues the next DMAs and THEN runs those 2 x MF MFMAs - the matrix pipe no longer idles through the
+            // cold LDS reads and the DMA issue of every piece start (wave timing: 580 of 4,950 clocks per piece). Pieces that end a slab
+            // keep the barrier at the end (the next slab's set-up has not run yet).
+            constexpr bool DEFER = SN_DEFER && SPLIT == 2 && C::PCH == 2 && NF >= 4 && !(SN_ABL & 2) && !SN_TIMING && !SN_DMA_LATE;
+            constexpr int GDEF = C::PCH * NF - 2;                // first deferred group of a piece
+            half8 xc[NPLM][MF], xn[NPLM][MF], wr[WD + 1][NPLM], wsp[DEFER ? 2 : 1];
             int ko1, ko2;
             auto issue_x = [&](half8(&dst)[NPLM][MF], int ko) {
                 if constexpr (SN_ABL & 32) return;
@@ -615,18 +625,22 @@ conv3d_f16_mfma(ConvArgs a)
                 long long x8q[SPLIT == 2 ? MF : 1][4];
                 v4i x8h[SPLIT == 2 ? MF : 1][2];
                 v3i x6[SPLIT == 2 ? MF : 1][2];                                    // 6-bit forms: a slot's 12 code bytes
-                lds_read128<0>(wr[0][0], wp);
-                if constexpr (SPLIT == 1) lds_read128<1024>(wr[0][1], wp);
-                if constexpr (WD == 2 && C::PCH * NF > 1) {
-                    lds_read128<C::MFRAG>(wr[1][0], wp);
-                    if constexpr (SPLIT == 1) lds_read128<C::MFRAG + 1024>(wr[1][1], wp);
-                }
+                auto first_frags = [&](unsigned wpx) {
+                    lds_read128<0>(wr[0][0], wpx);
+                    if constexpr (SPLIT == 1) lds_read128<1024>(wr[0][1], wpx);
+                    if constexpr (WD == 2 && C::PCH * NF > 1) {
+                        lds_read128<C::MFRAG>(wr[1][0], wpx);
+                        if constexpr (SPLIT == 1) lds_read128<C::MFRAG + 1024>(wr[1][1], wpx);
+                    }
+                };
+                const bool defer = DEFER && p + 1 < npiece;                  // this piece hands over to its successor in front of its last two groups
+                if (!DEFER || p == 0) first_frags(wp);                       // (else: requested by the previous piece, behind its barrier)
                 // next weight piece (the following piece of this slab, else the first piece of what comes next) and, behind it, the next
                 // slab's halo tile. SN_DMA_LATE: issued AFTER the first MFMA group of the piece instead of in front of it - every wave of the
                 // workgroup leaves the barrier at the same moment, so DMA issue code in front of the first MFMAs idles the matrix pipe of all
                 // four SIMDs for its whole length; behind the first group it runs under those MFMAs.
                 int hnow = 0;
-                auto issue_dmas = [&]() {
+                auto issue_dmas = [&](int p, int ch0, int wbi) {          // at the start of piece p (whose weights are in buffer wbi)
                     if (p + 1 < npiece) {
                         const int rem = wchunk - (ch0 + C::PCH);
                         stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
@@ -644,7 +658,7 @@ conv3d_f16_mfma(ConvArgs a)
                         hdone += kn;
                     }
                 };
-                if constexpr (!SN_DMA_LATE) issue_dmas();
+                if constexpr (!SN_DMA_LATE) { if (!DEFER || p == 0) issue_dmas(p, ch0, wbi); }
                 if constexpr (SN_TIMING >= 7) { t_dma = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                 static_for<0, C::PCH>([&](auto ccc) {
                     constexpr int cc = decltype(ccc)::value;
@@ -665,20 +679,31 @@ conv3d_f16_mfma(ConvArgs a)
                             constexpr bool SPR = SN_ESPREAD && SPLIT == 2 && SN_MX_B128 && NF - WD >= 2;   // (f16x3 / f16 kernels: conv2_x +2 %, the rest unchanged -> burst kept)
                             constexpr int PER = SPR ? (E + NF - WD - 1) / (NF - WD) : E;
                             constexpr int EQ = sn_e_after(n - 1, E, PER) + (WD == 2 ? sn_e_after(n - 2, E, PER) : 0);   // E reads younger than the awaited fragment
-                            if constexpr (WD == 2) {
-                                if constexpr (G + 2 < GT && !(SN_ABL & 16)) {
-                                    lds_read128<(G + 2) * C::MFRAG>(wr[nxt][0], wp);
-                                    if constexpr (SPLIT == 1) lds_read128<(G + 2) * C::MFRAG + 1024>(wr[nxt][1], wp);
+                            // weight fragment of a later group; the piece's last two groups (DEFER) keep theirs in wsp
+                            constexpr int Gn = WD == 2 ? G + 2 : (more_n ? G + 1 : (cc + 1) * NF);      // the group whose fragment is requested now
+                            if constexpr (Gn < GT && !(SN_ABL & 16)) {
+                                if constexpr (DEFER && Gn >= GDEF) lds_read128<Gn * C::MFRAG>(wsp[Gn - GDEF], wp);
+                                else {
+                                    lds_read128<Gn * C::MFRAG>(wr[nxt][0], wp);
+                                    if constexpr (SPLIT == 1) lds_read128<Gn * C::MFRAG + 1024>(wr[nxt][1], wp);
                                 }
-                                lgkm_wait<NPLM * ((G + 1 < GT ? 1 : 0) + (G + 2 < GT ? 1 : 0)) + EQ>();
-                            } else {
-                                constexpr int wo = (more_n ? (cc * NF + n + 1) : ((cc + 1) * NF)) * C::MFRAG;
-                                if constexpr ((more_n || more_c) && !(SN_ABL & 16)) {
-                                    lds_read128<wo>(wr[nxt][0], wp);
-                                    if constexpr (SPLIT == 1) lds_read128<wo + 1024>(wr[nxt][1], wp);
-                                }
-                                lgkm_wait<((more_n || more_c) ? NPLM : 0) + EQ>();
                             }
+                            auto group_wait = [&]() {
+                                if constexpr (WD == 2) lgkm_wait<NPLM * ((G + 1 < GT ? 1 : 0) + (G + 2 < GT ? 1 : 0)) + EQ>();
+                                else lgkm_wait<((more_n || more_c) ? NPLM : 0) + EQ>();
+                            };
+                            if constexpr (DEFER && G == GDEF) {
+                                if (defer) {
+                                    // hand the weight buffers over to the next piece HERE: everything this piece still needs is in registers
+                                    lgkm_wait<0>();
+                                    if (hnow >= HQ) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HQ) : "memory");
+                                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    wg_barrier();
+                                    first_frags(wbuf_a + (wbi ^ 1) * C::WBUF);
+                                } else group_wait();
+                            } else if constexpr (DEFER && G == GDEF + 1) {
+                                if (!defer) group_wait();
+                            } else group_wait();
                             if constexpr (!(SN_ABL & 4)) {
                                 if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(1);
                                 if constexpr (SPLIT == 1) {
@@ -689,14 +714,16 @@ conv3d_f16_mfma(ConvArgs a)
                                     for (int m = 0; m < MF; ++m)
                                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[1][m], acc[m][n], 0, 0, 0);
                                 }
+                                const half8 &w0 = (DEFER && G >= GDEF) ? wsp[(DEFER && G >= GDEF) ? G - GDEF : 0] : wr[cur][0];
 #pragma unroll
                                 for (int m = 0; m < MF; ++m)
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[0][m], acc[m][n], 0, 0, 0);
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xc[0][m], acc[m][n], 0, 0, 0);
                                 if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(0);
                             } else {
                                 asm volatile("" ::"v"(wr[cur][0]), "v"(xc[0][0]));
                             }
-                            if constexpr (SN_DMA_LATE && cc == 0 && n == 0) issue_dmas();
+                            if constexpr (DEFER && G == GDEF) { if (defer) issue_dmas(p + 1, ch0 + C::PCH, wbi ^ 1); }   // under this group's MFMAs
+                            if constexpr (SN_DMA_LATE && cc == 0 && n == 0) issue_dmas(p, ch0, wbi);
                             if constexpr (SPR) {
                                 constexpr int NX = MF * NPLM;
                                 static_for<0, E>([&](auto rc) {
@@ -839,7 +866,7 @@ conv3d_f16_mfma(ConvArgs a)
                     }
                 });
                 lgkm_wait<0>();
-                if constexpr (!(SN_ABL & 2)) {
+                if constexpr (!(SN_ABL & 2)) if (!defer) {
                     long long tq0 = 0, tq1 = 0;
                     if constexpr (SN_TIMING) { tq0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                     // next weight piece landed; the newest HQ halo DMAs (issued after it) may still fly
