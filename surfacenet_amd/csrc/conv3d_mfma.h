@@ -61,7 +61,10 @@
 #define SN_STATIC_PRIO 1   // +0.7 % on the 3-D f16x3 / f16m8 kernels (merge_conv_b -1.6 %); -0.8 % in f16 mode and on the 2-D kernels -> off there
 #endif
 #ifndef SN_DEFER
-#define SN_DEFER 1
+#define SN_DEFER 2       // 1: f16m8 kernels only; 2: also conv2_x / conv3_x in f16x3 (-3..6 %; conv1_x +4 % and the 2-D nets +1.4 % -> not there; conv4_x spills)
+#endif
+#ifndef SN_DEFER_X3_MAXACC
+#define SN_DEFER_X3_MAXACC 20
 #endif
 #ifndef SN_ESPREAD
 #define SN_ESPREAD 1
@@ -584,9 +587,9 @@ conv3d_f16_mfma(ConvArgs a)
             // piece's fragments and issues the next DMAs and THEN runs those 2 x MF MFMAs - the matrix pipe no longer idles through the
             // cold LDS reads and the DMA issue of every piece start (wave timing: 580 of 4,950 clocks per piece). Pieces that end a slab
             // keep the barrier at the end (the next slab's set-up has not run yet).
-            constexpr bool DEFER = SN_DEFER && SPLIT == 2 && C::PCH == 2 && NF >= 4 && !(SN_ABL & 2) && !SN_TIMING && !SN_DMA_LATE;
+            constexpr bool DEFER = SN_DEFER && NF >= 4 && (SPLIT == 2 || (SN_DEFER >= 2 && SPLIT == 1 && K2D == 0 && MF * NF <= SN_DEFER_X3_MAXACC && DIL == 1)) && BUFH && !(SN_ABL & 2) && !SN_TIMING && !SN_DMA_LATE;
             constexpr int GDEF = C::PCH * NF - 2;                // first deferred group of a piece
-            half8 xc[NPLM][MF], xn[NPLM][MF], wr[WD + 1][NPLM], wsp[DEFER ? 2 : 1];
+            half8 xc[NPLM][MF], xn[NPLM][MF], wr[WD + 1][NPLM], wsp[DEFER ? 2 : 1][NPLM];
             int ko1, ko2;
             auto issue_x = [&](half8(&dst)[NPLM][MF], int ko) {
                 if constexpr (SN_ABL & 32) return;
@@ -682,8 +685,10 @@ conv3d_f16_mfma(ConvArgs a)
                             // weight fragment of a later group; the piece's last two groups (DEFER) keep theirs in wsp
                             constexpr int Gn = WD == 2 ? G + 2 : (more_n ? G + 1 : (cc + 1) * NF);      // the group whose fragment is requested now
                             if constexpr (Gn < GT && !(SN_ABL & 16)) {
-                                if constexpr (DEFER && Gn >= GDEF) lds_read128<Gn * C::MFRAG>(wsp[Gn - GDEF], wp);
-                                else {
+                                if constexpr (DEFER && Gn >= GDEF) {
+                                    lds_read128<Gn * C::MFRAG>(wsp[Gn - GDEF][0], wp);
+                                    if constexpr (SPLIT == 1) lds_read128<Gn * C::MFRAG + 1024>(wsp[Gn - GDEF][1], wp);
+                                } else {
                                     lds_read128<Gn * C::MFRAG>(wr[nxt][0], wp);
                                     if constexpr (SPLIT == 1) lds_read128<Gn * C::MFRAG + 1024>(wr[nxt][1], wp);
                                 }
@@ -706,15 +711,16 @@ conv3d_f16_mfma(ConvArgs a)
                             } else group_wait();
                             if constexpr (!(SN_ABL & 4)) {
                                 if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                                const half8(&wg)[NPLM] = (DEFER && G >= GDEF) ? wsp[(DEFER && G >= GDEF) ? G - GDEF : 0] : wr[cur];
+                                const half8 &w0 = wg[0];
                                 if constexpr (SPLIT == 1) {
 #pragma unroll
                                     for (int m = 0; m < MF; ++m)
-                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][1], xc[0][m], acc[m][n], 0, 0, 0);
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[1], xc[0][m], acc[m][n], 0, 0, 0);
 #pragma unroll
                                     for (int m = 0; m < MF; ++m)
-                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][0], xc[1][m], acc[m][n], 0, 0, 0);
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xc[1][m], acc[m][n], 0, 0, 0);
                                 }
-                                const half8 &w0 = (DEFER && G >= GDEF) ? wsp[(DEFER && G >= GDEF) ? G - GDEF : 0] : wr[cur][0];
 #pragma unroll
                                 for (int m = 0; m < MF; ++m)
                                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xc[0][m], acc[m][n], 0, 0, 0);
