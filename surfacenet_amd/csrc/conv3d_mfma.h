@@ -516,7 +516,8 @@ conv3d_f16_mfma(ConvArgs a)
 #if SN_STATIC_PRIO
     // static priority for the younger half of an 8-wave workgroup (MI355X_MICROARCH.md, two waves per SIMD): waves 4-7 lose
     // the VALU arbitration to waves 0-3 on every segment otherwise
-    if (C::NW == 8 && SPLIT != 0 && K2D == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+    // (r2z A/B with the deferred barrier: merge_conv_a/b -1.2 %, conv4_x 0, conv1_x / conv2_x +1..3 % -> only where a wave owns >= 7 cout fragments)
+    if (C::NW == 8 && SPLIT != 0 && K2D == 0 && (NF >= 7 || DIL == 2) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
     int xb = 0;     // halo / tap-table buffer holding the current slab
     int wbi = 0;    // weight buffer holding the current piece
