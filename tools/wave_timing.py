@@ -2,7 +2,12 @@
 """tools/wave_timing.py — where do the conv kernels' waves wait? Needs a diagnostic build of the library:
     hipcc ... -DSN_TIMING=1 (conv3d_mfma.h) -> SURFACENET_HIP_LIB=<that .so> python tools/wave_timing.py
 Every wave accumulates shader-clock totals (whole kernel, the vmcnt wait in front of each per-piece barrier, the barrier itself); the
-script runs the headline batch a few times and prints, per layer, the share of wave time spent in the two waits."""
+script runs the headline batch a few times and prints, per layer, the share of wave time spent in the two waits.
+-DSN_TIMING=3..8 (f16m8 kernels, i.e. merge_conv_a/b) put SEGMENT times of a weight piece into the two wait columns instead, odd values for
+waves >= NW/2 (the prioritised half), even for the others: 3/4 = piece start -> MX step done | MX step done -> end of chunk 1;
+5/6 = piece start -> end of chunk 0 | the MX step; 7/8 = piece start -> DMAs issued and first fragments landed | the rest of chunk 0.
+The printed "wait/piece" figures then average over ALL waves and pieces: multiply by 2 / (share of pieces with p > 0 in a slab, 3/4 for the
+merge layers) to get clocks per piece of the measured half. These builds disable the deferred barrier."""
 import ctypes
 import os
 import sys
