@@ -126,6 +126,12 @@ void *sn_dev_alloc(sn_ctx *ctx, size_t bytes);
 int sn_dev_free(sn_ctx *ctx, void *p_dev);
 int sn_memcpy_h2d(sn_ctx *ctx, void *dst_dev, const void *src, size_t bytes);
 int sn_memcpy_d2h(sn_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
+/* Pipelined readback for loops that enqueue the next batch before they fetch the previous one (the reference's hot loop collects a
+ * sparse list per cube and batch, main_reconstruct.py:126-160): sn_mark records point `slot` (0..7) on the context's stream;
+ * sn_memcpy_d2h_after copies on a second stream as soon as that point has been reached and returns when the copy is done - work
+ * enqueued on the context's stream AFTER the mark keeps running meanwhile (sn_memcpy_d2h would wait for all of it). */
+int sn_mark(sn_ctx *ctx, int slot);
+int sn_memcpy_d2h_after(sn_ctx *ctx, int slot, void *dst, const void *src_dev, size_t bytes);
 /* The HIP stream (hipStream_t) every asynchronous entry point of this context is ordered on, for interop: record / wait
  * events on it, or wrap it (e.g. torch.cuda.ExternalStream) to order collectives against the kernels without host syncs. */
 void *sn_stream(sn_ctx *ctx);

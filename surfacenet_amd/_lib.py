@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "sn_create", "sn_destroy", "sn_last_error", "sn_version", "sn_synchronize", "sn_set_precision", "sn_get_precision", "sn_stream",
     "sn_load_weights", "sn_set_images", "sn_set_cameras",
     "sn_cvc", "sn_forward", "sn_cvc_forward", "sn_relative_weights", "sn_viewpair_weights", "sn_color_fuse", "sn_color_fuse_dev",
-    "sn_dev_alloc", "sn_dev_free", "sn_memcpy_h2d", "sn_memcpy_d2h",
+    "sn_dev_alloc", "sn_dev_free", "sn_memcpy_h2d", "sn_memcpy_d2h", "sn_mark", "sn_memcpy_d2h_after",
     "sn_cvc_forward_dev", "sn_cvc_dev", "sn_forward_dev",
     "sn_ray_pool", "sn_ray_pool_dev", "sn_dense2sparse", "sn_dense2sparse_dev",
     "sn_simil_load_weights", "sn_crop_patches", "sn_patch2embedding", "sn_crop_embed", "sn_embeddingpair2simil", "sn_embeddings2simil",
@@ -80,6 +80,8 @@ def load():
         "sn_dev_free": (c_int, [c_void_p, c_void_p]),
         "sn_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
         "sn_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+        "sn_mark": (c_int, [c_void_p, c_int]),
+        "sn_memcpy_d2h_after": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
         "sn_cvc_forward_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 8),
         "sn_cvc_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5),
         "sn_forward_dev": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4),

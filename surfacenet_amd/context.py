@@ -289,6 +289,15 @@ class Context(object):
         assert arr.flags["C_CONTIGUOUS"]
         _lib.check(self._lib.sn_memcpy_d2h(self._h, _lib.ptr(arr), src_dev, arr.nbytes))
 
+    def mark(self, slot):
+        """Records point `slot` (0..7) on the context's stream for d2h_after."""
+        _lib.check(self._lib.sn_mark(self._h, int(slot)))
+
+    def d2h_after(self, slot, arr, src_dev):
+        """d2h that waits only for the work enqueued BEFORE mark(slot), not for what was enqueued since."""
+        assert arr.flags["C_CONTIGUOUS"]
+        _lib.check(self._lib.sn_memcpy_d2h_after(self._h, int(slot), _lib.ptr(arr), src_dev, arr.nbytes))
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         p = self.dev_alloc(max(arr.nbytes, 16))

@@ -519,6 +519,8 @@ void sn_destroy(sn_ctx *c)
     comm_destroy_impl(c);
     for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : c->marks) if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (void *p : c->owned) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1118,6 +1120,27 @@ int sn_memcpy_d2h(sn_ctx *c, void *dst, const void *src, size_t bytes)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
+int sn_mark(sn_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= 8) return fail(SN_ERR_ARG, "sn_mark: slot must be 0..7");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->marks[slot]) HIPCHK(hipEventCreateWithFlags(&c->marks[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->marks[slot], c->stream));
+    return SN_OK;
+}
+
+int sn_memcpy_d2h_after(sn_ctx *c, int slot, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(SN_ERR_ARG, "null argument");
+    if (slot < 0 || slot >= 8 || !c->marks[slot]) return fail(SN_ERR_STATE, "sn_memcpy_d2h_after: slot %d was never marked", slot);
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->marks[slot], 0));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
     return SN_OK;
 }
 

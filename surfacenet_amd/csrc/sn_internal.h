@@ -72,6 +72,8 @@ struct ProfStat { std::string name; double ms = 0; int64_t launches = 0; double 
 struct sn_ctx {
     int device = 0, s = 32, max_samples = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;      // sn_memcpy_d2h_after: device-to-host copies that overlap later work on `stream`
+    hipEvent_t marks[8] = {};               // sn_mark: points on `stream` those copies wait for
     // images / cameras
     int V_img = 0, V_cam = 0;
     uint8_t *img_base = nullptr; long long *img_off = nullptr; int *img_h = nullptr, *img_w = nullptr;
