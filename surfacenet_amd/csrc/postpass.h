@@ -26,6 +26,7 @@
 namespace sn {
 
 constexpr int RP_NT = 1024;
+constexpr int RP_LIST = 8192;        // selected voxels of a (cube, view) listed in LDS (2 x 32 KB)
 constexpr unsigned long long RP_EMPTY = ~0ull;
 constexpr unsigned RP_NONE = 0xFFFFFFFFu;
 
@@ -87,7 +88,6 @@ __device__ __forceinline__ void rp_vote(uint8_t *votes, unsigned i, unsigned mul
 __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
 {
     __shared__ int sh_i[4];          // m, dmin, vote-for-voxel-0 flag, unused
-    __shared__ int sh_red[RP_NT / 64];
     const int tid = threadIdx.x;
     const int cube = blockIdx.y, entry = blockIdx.x, E = 2 * a.n_vp;
     const int s = a.s, V3 = s * s * s;
@@ -117,17 +117,24 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
 
     auto selected = [&](int i, _Float16 &p) { p = (_Float16)pred[i]; return !a.use_thresh || p > thr; };
 
-    // ---- pass 1: count the selected voxels
-    int cnt = 0;
-    for (int i = tid; i < V3; i += RP_NT) { _Float16 p; cnt += selected(i, p) ? 1 : 0; }
-    for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if ((tid & 63) == 0) sh_red[tid >> 6] = cnt;
-    if (tid == 0) { sh_i[1] = 0x7fffffff; sh_i[2] = 0; }
+    // ---- pass 1: count the selected voxels and list them (any order: every later step is a max / an add). With the list (up to
+    // RP_LIST voxels, i.e. every realistic surface) the passes below touch only the selected voxels with all lanes busy; without it
+    // a wave runs the fp64 projection whenever ANY of its 64 lanes holds a selected voxel - 32 times per lane at 1 % selected as at 10 %.
+    __shared__ unsigned sh_list[RP_LIST], sh_q[RP_LIST];
+    if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0x7fffffff; sh_i[2] = 0; }
     __syncthreads();
-    if (tid == 0) { int m = 0; for (int i = 0; i < RP_NT / 64; ++i) m += sh_red[i]; sh_i[0] = m; }
+    for (int i = tid; i < V3; i += RP_NT) {
+        _Float16 p;
+        if (selected(i, p)) {
+            const int pos = atomicAdd(&sh_i[0], 1);
+            if (pos < RP_LIST) sh_list[pos] = (unsigned)i;
+        }
+    }
     __syncthreads();
     const int m = sh_i[0];
     if (m == 0) return;
+    const bool listed = m <= RP_LIST;
+    const int n_it = listed ? m : V3;                       // iteration space of passes 3-5: list positions, or all voxels
     unsigned cap = 64;
     while (cap < 2u * (unsigned)m) cap <<= 1;
     const unsigned mask = cap - 1;
@@ -144,10 +151,11 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
 
     // ---- pass 3: project, insert pixel and cell, keep the largest voxel index per cell
     int dmin_t = 0x7fffffff;
-    for (int i = tid; i < V3; i += RP_NT) {
+    for (int j = tid; j < n_it; j += RP_NT) {
+        const int i = listed ? (int)sh_list[j] : j;
         _Float16 p;
         unsigned q = RP_NONE;
-        if (selected(i, p)) {
+        if (listed || selected(i, p)) {
             const int kz = i % s, jy = (i / s) % s, ix = i / (s * s);
             const double X = __dadd_rn(__dmul_rn((double)ix, r), x0);
             const double Y = __dadd_rn(__dmul_rn((double)jy, r), y0);
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
                 dmin_t = min(dmin_t, di);
             }
         }
-        cslot[i] = q;
+        if (listed) sh_q[j] = q; else cslot[i] = q;
     }
     for (int o = 32; o; o >>= 1) dmin_t = min(dmin_t, __shfl_xor(dmin_t, o));
     if ((tid & 63) == 0) atomicMin(&sh_i[1], dmin_t);
@@ -181,8 +189,9 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
     };
 
     // ---- pass 4: every cell's voxel bids for its pixel
-    for (int i = tid; i < V3; i += RP_NT) {
-        const unsigned q = cslot[i];
+    for (int j = tid; j < n_it; j += RP_NT) {
+        const int i = listed ? (int)sh_list[j] : j;
+        const unsigned q = listed ? sh_q[j] : cslot[i];
         if (q == RP_NONE || rp_ld(cell_idx + q) != (unsigned)i) continue;
         const _Float16 p = (_Float16)pred[i];
         if (!(p > (_Float16)0.f)) continue;                 // a stored 0 is indistinguishable from an empty cell
@@ -193,8 +202,9 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
 
     // ---- pass 5: winners vote
     uint8_t *votes = a.votes + (size_t)cube * V3;
-    for (int i = tid; i < V3; i += RP_NT) {
-        const unsigned q = cslot[i];
+    for (int j = tid; j < n_it; j += RP_NT) {
+        const int i = listed ? (int)sh_list[j] : j;
+        const unsigned q = listed ? sh_q[j] : cslot[i];
         if (q == RP_NONE || rp_ld(cell_idx + q) != (unsigned)i) continue;
         const _Float16 p = (_Float16)pred[i];
         const unsigned long long ck = rp_ld(cell_key + q);
