@@ -681,7 +681,7 @@ conv3d_f16_mfma(ConvArgs a)
                             // per wave (8 waves at once, right after the barrier) filled the LDS queue, and the weight fragment of group WD+1 - issued
                             // behind the burst, returned in order - made chunk 0 take 1,640 clocks for 450 of MFMA issue (wave timing, SN_TIMING 5)
                             constexpr bool SPR = SN_ESPREAD && SPLIT == 2 && SN_MX_B128 && NF - WD >= 2;   // (f16x3 / f16 kernels: conv2_x +2 %, the rest unchanged -> burst kept)
-                            constexpr int PER = SPR ? (E + NF - WD - 1) / (NF - WD) : E;
+                            constexpr int PER = SPR ? (E + NF - WD - 1) / (NF - WD > 0 ? NF - WD : 1) : E;
                             constexpr int EQ = sn_e_after(n - 1, E, PER) + (WD == 2 ? sn_e_after(n - 2, E, PER) : 0);   // E reads younger than the awaited fragment
                             // weight fragment of a later group; the piece's last two groups (DEFER) keep theirs in wsp
                             constexpr int Gn = WD == 2 ? G + 2 : (more_n ? G + 1 : (cc + 1) * NF);      // the group whose fragment is requested now
