@@ -63,6 +63,9 @@
 #ifndef SN_DEFER
 #define SN_DEFER 2       // 1: f16m8 kernels only; 2: also conv2_x / conv3_x in f16x3 (-3..6 %; conv1_x +4 % and the 2-D nets +1.4 % -> not there; conv4_x spills)
 #endif
+#ifndef SN_DEFER_X3_GROUPS
+#define SN_DEFER_X3_GROUPS 2     // deferred groups of an f16x3 piece (1: conv2_x +4 %)
+#endif
 #ifndef SN_DEFER_X3_MAXACC
 #define SN_DEFER_X3_MAXACC 20
 #endif
@@ -589,8 +592,9 @@ conv3d_f16_mfma(ConvArgs a)
             // cold LDS reads and the DMA issue of every piece start (wave timing: 580 of 4,950 clocks per piece). Pieces that end a slab
             // keep the barrier at the end (the next slab's set-up has not run yet).
             constexpr bool DEFER = SN_DEFER && NF >= 4 && (SPLIT == 2 || (SN_DEFER >= 2 && SPLIT == 1 && K2D == 0 && MF * NF <= SN_DEFER_X3_MAXACC && DIL == 1)) && BUFH && !(SN_ABL & 2) && !SN_TIMING && !SN_DMA_LATE;
-            constexpr int GDEF = C::PCH * NF - 2;                // first deferred group of a piece
-            half8 xc[NPLM][MF], xn[NPLM][MF], wr[WD + 1][NPLM], wsp[DEFER ? 2 : 1][NPLM];
+            constexpr int NDEF = (SPLIT == 1 && SN_DEFER_X3_GROUPS == 1) ? 1 : 2;   // f16x3: one group = 3 x MF MFMAs already covers the cold reads
+            constexpr int GDEF = C::PCH * NF - NDEF;             // first deferred group of a piece
+            half8 xc[NPLM][MF], xn[NPLM][MF], wr[WD + 1][NPLM], wsp[DEFER ? NDEF : 1][NPLM];
             int ko1, ko2;
             auto issue_x = [&](half8(&dst)[NPLM][MF], int ko) {
                 if constexpr (SN_ABL & 32) return;
@@ -707,7 +711,7 @@ conv3d_f16_mfma(ConvArgs a)
                                     wg_barrier();
                                     first_frags(wbuf_a + (wbi ^ 1) * C::WBUF);
                                 } else group_wait();
-                            } else if constexpr (DEFER && G == GDEF + 1) {
+                            } else if constexpr (DEFER && G > GDEF) {
                                 if (!defer) group_wait();
                             } else group_wait();
                             if constexpr (!(SN_ABL & 4)) {
