@@ -60,6 +60,9 @@
 #ifndef SN_STATIC_PRIO
 #define SN_STATIC_PRIO 1   // +0.7 % on the 3-D f16x3 / f16m8 kernels (merge_conv_b -1.6 %); -0.8 % in f16 mode and on the 2-D kernels -> off there
 #endif
+#ifndef SN_MX6_B128
+#define SN_MX6_B128 0     // 1: whole-slot ds_read_b128 (cheaper in the LDS: 4.6 vs 8.4 clocks per wave instruction, lds_probe) but 8 more live registers: merge_conv_b +0.5 %
+#endif
 #ifndef SN_DEFER
 #define SN_DEFER 2       // 1: f16m8 kernels only; 2: also conv2_x / conv3_x in f16x3 (-3..6 %; conv1_x +4 % and the 2-D nets +1.4 % -> not there; conv4_x spills)
 #endif
@@ -752,7 +755,7 @@ conv3d_f16_mfma(ConvArgs a)
                                         } else if constexpr (r <= NX + 2 * MF) {
                                             constexpr int m = (r - NX - 1) / 2, sl = (r - NX - 1) % 2;
                                             const unsigned ad = xaddr[m] + C::XPLANE + (unsigned)(int)(sl ? (k2 >> 32) : k2);
-                                            if constexpr (SN_MX_FMT != 0) lds_read96i<0>(x6[m][sl], ad);   // the 12 code bytes of a slot = half of the lane's 192-bit operand
+                                            if constexpr (SN_MX_FMT != 0 && !SN_MX6_B128) lds_read96i<0>(x6[m][sl], ad);   // the 12 code bytes of a slot = half of the lane's 192-bit operand
                                             else lds_read128i<0>(x8h[m][sl], ad);                         // whole 16-byte slot [fp8(hi) x8 | fp8(lo*2^12) x8]
                                         } else {
                                             lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);       // tap offsets of the next piece's MX step
@@ -770,8 +773,13 @@ conv3d_f16_mfma(ConvArgs a)
                                         constexpr int m = decltype(mc)::value;
                                         if constexpr (SN_MX_B128 && SN_MX_FMT != 0) {
                                             const unsigned ad = xaddr[m] + C::XPLANE;               // the 12 code bytes of two slots = the lane's 192-bit operand
-                                            lds_read96i<0>(x6[m][0], ad + (unsigned)(int)k2);
-                                            lds_read96i<0>(x6[m][1], ad + (unsigned)(int)(k2 >> 32));
+                                            if constexpr (SN_MX6_B128) {
+                                                lds_read128i<0>(x8h[m][0], ad + (unsigned)(int)k2);
+                                                lds_read128i<0>(x8h[m][1], ad + (unsigned)(int)(k2 >> 32));
+                                            } else {
+                                                lds_read96i<0>(x6[m][0], ad + (unsigned)(int)k2);
+                                                lds_read96i<0>(x6[m][1], ad + (unsigned)(int)(k2 >> 32));
+                                            }
                                         } else if constexpr (SN_MX_B128) {
                                             const unsigned ad = xaddr[m] + C::XPLANE;               // whole 16-byte slots [fp8(hi) x8 | fp8(lo*2^12) x8]
                                             lds_read128i<0>(x8h[m][0], ad + (unsigned)(int)k2);
@@ -813,7 +821,18 @@ conv3d_f16_mfma(ConvArgs a)
                             if constexpr (SN_MX_B128 && SN_MX_FMT != 0) {
                                 // the second slot's three dwords cannot be read in place (a register tuple starts on an even register): 3 v_mov's per
                                 // fragment. Tried: reading it as 32 + 64 bits (lands in place, but the 64-bit read is 4-byte aligned) - merge_conv_b +23 %
-                                x8[m] = __builtin_shufflevector(x6[m][0], x6[m][1], 0, 1, 2, 3, 4, 5, -1, -1);
+                                // SN_MX6_B128: the slots are read whole (ds_read_b128: 4.6 LDS clocks per wave instruction under load, ds_read_b96: 8.4;
+                                // tools/probe/lds_probe.hip) and the pad dword of the first is overwritten when the second is moved down by one register
+                                if constexpr (SN_MX6_B128) {
+                                    // (the empty asm pins the copies BEHIND the chunk-end wait: to the compiler the registers were complete when the
+                                    // reads were issued, and it is free to move plain copies of them up there)
+                                    asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
+                                    x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
+                                }
+                                else {
+                                    asm volatile("" : "+v"(x6[m][0]), "+v"(x6[m][1]));
+                                    x8[m] = __builtin_shufflevector(x6[m][0], x6[m][1], 0, 1, 2, 3, 4, 5, -1, -1);
+                                }
                             } else if constexpr (SN_MX_B128) {
                                 x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 3, 4, 5, 6, 7);
                             } else {
