@@ -1144,6 +1144,10 @@ int sn_memcpy_d2h_after(sn_ctx *c, int slot, void *dst, const void *src, size_t 
     return SN_OK;
 }
 
+// Test hook (not part of the ABI header): the host-side 6-bit encoder the weight packer uses, so that a CPU test can pin it against the
+// format's decode table (tests/test_abi.py) - the device side of the format is pinned by tools/probe/fp6_probe.hip.
+int sn_debug_mx6_encode(float v, int fmt) { return (fmt == 2 || fmt == 3) ? (int)mx6_encode(v, fmt) : -1; }
+
 // Diagnostic builds only (-DSN_TIMING=1, conv3d_mfma.h): per-layer shader-clock totals {kernel, vmcnt wait, barrier wait, pieces} summed over
 // waves, in layer-bit order (names: sn_synchronize's message order). Not part of the ABI header; reads and clears the slots.
 int sn_debug_timing(sn_ctx *c, unsigned long long *out, int n_layers, char *names, int names_cap)

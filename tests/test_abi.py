@@ -61,3 +61,39 @@ def test_code_object_is_gfx950_only(built):
     out = subprocess.run(["strings", built.LIB_PATH], capture_output=True, text=True).stdout
     targets = set(re.findall(r"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", out))
     assert targets == {"gfx950"}, targets
+
+
+def _dec6(code, fmt):
+    """fp6 e2m3 (fmt 2, bias 1) / bf6 e3m2 (fmt 3, bias 3) code -> value (OCP MX formats; tools/probe/fp6_probe.hip dec6)."""
+    mb, bias = (3, 1) if fmt == 2 else (2, 3)
+    s, E, M = code >> 5, (code & 31) >> mb, code & ((1 << mb) - 1)
+    v = M * 2.0 ** (1 - bias - mb) if E == 0 else ((1 << mb) + M) * 2.0 ** (E - bias - mb)
+    return -v if s else v
+
+
+@pytest.mark.parametrize("fmt", [2, 3])
+def test_host_mx6_encoder_matches_the_format(built, fmt):
+    """The weight packer's 6-bit encoder (sn_api.hip mx6_encode): exact on every representable value, round-to-nearest-even on the
+    midpoints, saturating, monotone - the properties the device-side conversions have (fp6_probe) and the CPU model assumes."""
+    import ctypes
+    lib = built.load()
+    enc = lib.sn_debug_mx6_encode
+    enc.restype = ctypes.c_int
+    enc.argtypes = [ctypes.c_float, ctypes.c_int]
+    vals = [_dec6(c, fmt) for c in range(32)]
+    assert vals == sorted(vals) and vals[0] == 0.0
+    for c in range(64):
+        if c == 32:
+            continue                                         # -0
+        assert enc(_dec6(c, fmt), fmt) == c, c
+    for c in range(31):                                      # midpoints: ties to the even code; just off the midpoint: nearest
+        lo, hi = vals[c], vals[c + 1]
+        mid = (lo + hi) / 2
+        assert enc(mid, fmt) == (c if c % 2 == 0 else c + 1), (c, mid)
+        assert enc(mid - (hi - lo) / 64, fmt) == c and enc(mid + (hi - lo) / 64, fmt) == c + 1
+        assert enc(-mid, fmt) == 32 + (c if c % 2 == 0 else c + 1)
+    top = vals[31]
+    assert top == (7.5 if fmt == 2 else 28.0)
+    assert enc(top * 1.01, fmt) == 31 and enc(1e30, fmt) == 31 and enc(-1e30, fmt) == 63
+    assert enc(vals[1] / 4, fmt) == 0 and enc(float("nan"), fmt) == 0
+    assert enc(1.0, 0) == -1

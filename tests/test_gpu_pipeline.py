@@ -146,3 +146,32 @@ def test_sharded_scene_two_processes_equals_single_process(gpu_required):
         assert p.exitcode == 0
     for rank, full in res:
         test_dist_cpu._same_scene(full, want)
+
+
+def test_marked_readback_sees_its_own_batch(gpu_required):
+    """sn_mark / sn_memcpy_d2h_after (reconstruct.SparseLoop.run_many's readback): the copy waits for the work enqueued BEFORE the mark
+    only - it returns the data as of the mark even when later work on the context's stream has already been enqueued to overwrite
+    the buffer's source - and an unmarked slot is an error, not a hang."""
+    import surfacenet_amd as sn
+    with sn.Context(cube_D=8, max_samples=2) as ctx:
+        a = np.arange(1 << 20, dtype=np.float32)
+        b = -a
+        dev = ctx.dev_alloc(a.nbytes)
+        keep = ctx.dev_alloc(a.nbytes)
+        got = np.empty_like(a)
+        with pytest.raises(sn.SurfaceNetHipError):
+            ctx.d2h_after(5, got, dev)                          # slot 5 was never marked
+        with pytest.raises(sn.SurfaceNetHipError):
+            ctx.mark(8)
+        ctx.h2d(dev, a)
+        ctx.mark(0)
+        ctx.h2d(keep, b)                                        # later work on the stream (does not touch dev)
+        ctx.d2h_after(0, got, dev)
+        assert np.array_equal(got, a)
+        ctx.h2d(dev, b)
+        ctx.mark(1)
+        ctx.d2h_after(1, got, dev)
+        assert np.array_equal(got, b)
+        ctx.d2h_after(0, got, keep)                             # an old mark stays valid: everything before it has long completed
+        assert np.array_equal(got, b)
+        ctx.dev_free(dev); ctx.dev_free(keep)
