@@ -85,6 +85,9 @@
 #ifndef SN_ROWGAP_3x3
 #define SN_ROWGAP_3x3 4
 #endif
+#ifndef SN_ROWGAP_2D
+#define SN_ROWGAP_2D 2   // 2-D nets (32 bytes per halo pixel, 10-pixel rows): fragment rows 2 apart = 640 bytes = 128 mod 256: conflict-free (lds_probe)
+#endif
 #ifndef SN_ROWGAP_DIL2
 #define SN_ROWGAP_DIL2 4
 #endif
@@ -476,6 +479,7 @@ conv3d_f16_mfma(ConvArgs a)
         else if constexpr (PMAP) { hx = 2 * (wave & 3) + (m >> 1); hy = 4 * (wave >> 2) + 2 * (m & 1) + (v >> 3); hz = v & 7; }
         else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 4) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
         else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 2) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
+        else if constexpr (K2D == 1 && SN_ROWGAP_2D == 2 && C::VS == 32) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
         else { hx = wave * C::XS + (m >> 2); hy = 2 * (m & 3) + (v >> 3); hz = v & 7; }
     };
     int xbase[MF];
@@ -946,12 +950,15 @@ conv3d_f16_mfma(ConvArgs a)
             const int Do = D >> 1;
             const size_t VOLo = (size_t)DX * Do * Do;
             constexpr int YX = C::F4 ? 4 : 8;                       // lane distance of the row partner
+            // R2: the two rows of a fragment lie 2 apart (conflict-free LDS reads, SN_ROWGAP_2D): the row partner of a pixel is the SAME lane of
+            // fragment m ^ 1 (rows r and r + 1), every lane row of fragment m = 0, 2 writes one pooled row
+            constexpr bool R2 = (K2D == 1 && SN_ROWGAP_2D == 2 && C::VS == 32);   // (64-byte pixels, f16 mode: adjacent rows are already 640 bytes apart)
 #pragma unroll
-            for (int m = 0; m < MF; ++m) {
+            for (int m = 0; m < MF; m += (R2 ? 2 : 1)) {
                 int hx_, hy_, hz_;
                 frag_xyz(m, hx_, hy_, hz_);
                 const int gx = x0 + hx_, gy = y0 + hy_, gz = z0 + hz_;
-                const bool writer = !(v & 1) && !(v & YX) && gx < DX && gy < D && gz < D;     // D is even: the whole quad is inside
+                const bool writer = !(v & 1) && (R2 || !(v & YX)) && gx < DX && gy < D && gz < D;     // D is even: the whole quad is inside
                 const size_t vlin = ((size_t)gx * Do + (gy >> 1)) * Do + (gz >> 1);
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
@@ -963,8 +970,9 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float y = fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f);
+                        if constexpr (R2) y = fmaxf(y, fmaxf(acc[m + 1 < MF ? m + 1 : m][n][r] * sc[r] + sh[r], 0.f));
                         y = fmaxf(y, __shfl_xor(y, 1));
-                        y = fmaxf(y, __shfl_xor(y, YX));
+                        if constexpr (!R2) y = fmaxf(y, __shfl_xor(y, YX));
                         bad |= !(y <= kF16Max);
                         if constexpr (OSPLIT == 1) {
                             _Float16 hh, ll;
