@@ -86,10 +86,11 @@
 #define SN_ROWGAP_3x3 4
 #endif
 #ifndef SN_ROWGAP_2D
-#define SN_ROWGAP_2D 2   // 2-D nets (32 bytes per halo pixel, 10-pixel rows): fragment rows 2 apart = 640 bytes = 128 mod 256: conflict-free (lds_probe)
+#define SN_ROWGAP_2D 4   // 2-D nets (32 bytes per halo pixel, 10-pixel rows, two channel groups per pass): a fragment's rows 4 apart = 1,280 bytes = 256 mod 512:
+                         // the 32 lanes of an LDS pass then cover 512 distinct bytes (lds_probe: 37 vs 67 clocks per read under load)
 #endif
 #ifndef SN_ROWGAP_DIL2
-#define SN_ROWGAP_DIL2 4
+#define SN_ROWGAP_DIL2 2
 #endif
 #ifndef SN_WDIST
 #define SN_WDIST 2        // weight fragments are fetched from LDS this many MFMA groups ahead of their use (1 or 2). A wave that holds the SIMD's
@@ -480,6 +481,7 @@ conv3d_f16_mfma(ConvArgs a)
         else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 4) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
         else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 2) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
         else if constexpr (K2D == 1 && SN_ROWGAP_2D == 2 && C::VS == 32) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
+        else if constexpr (K2D == 1 && SN_ROWGAP_2D == 4 && C::VS == 32) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
         else { hx = wave * C::XS + (m >> 2); hy = 2 * (m & 3) + (v >> 3); hz = v & 7; }
     };
     int xbase[MF];
@@ -952,7 +954,7 @@ conv3d_f16_mfma(ConvArgs a)
             constexpr int YX = C::F4 ? 4 : 8;                       // lane distance of the row partner
             // R2: the two rows of a fragment lie 2 apart (conflict-free LDS reads, SN_ROWGAP_2D): the row partner of a pixel is the SAME lane of
             // fragment m ^ 1 (rows r and r + 1), every lane row of fragment m = 0, 2 writes one pooled row
-            constexpr bool R2 = (K2D == 1 && SN_ROWGAP_2D == 2 && C::VS == 32);   // (64-byte pixels, f16 mode: adjacent rows are already 640 bytes apart)
+            constexpr bool R2 = (K2D == 1 && (SN_ROWGAP_2D == 2 || SN_ROWGAP_2D == 4) && C::VS == 32);   // (64-byte pixels, f16 mode: adjacent rows are already 640 bytes apart)
 #pragma unroll
             for (int m = 0; m < MF; m += (R2 ? 2 : 1)) {
                 int hx_, hy_, hz_;

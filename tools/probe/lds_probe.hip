@@ -107,6 +107,32 @@ int main()
     for (int k = 1; k < 4; ++k)
         printf("8 waves: rows 640 B apart, quarters 0 and %d at 0, the other two at 160 / 320 B : %.1f clk/read\n", k,
                run<128>(pat([k](int l) { int v = l & 15, kq = l >> 4; int o = (kq == 0 || kq == k) ? 0 : 160; return (unsigned)((v >> 3) * 640 + (v & 7) * 16 + o); }), 8));
+    // the kernels' own activation-fragment reads: every K-chunk of a channel slab (4 consecutive K groups = the 4 lane quarters), fragment 0,
+    // 8 waves; group g = tap * CS8 + channel group (conv3d_mfma.h write_koff), tap = ((dx * 3) + dy) * 3 + dz (2-D: dy * 3 + dz)
+    struct Cfg { const char *name; int vs, cs8, hy, hz, dil, ntap, gap; };
+    const Cfg cfgs[] = {
+        {"merge / conv1 (16 B, 1 group, rows 4 apart)", 16, 1, 10, 10, 1, 27, 4}, {"merge / conv1, rows 1 apart (EPI_SIDEPOOL map)", 16, 1, 10, 10, 1, 27, 1},
+        {"conv2/3 f16x3 (32 B, 2 groups, rows 4 apart)", 32, 2, 10, 10, 1, 27, 4}, {"conv2/3, rows 2 apart", 32, 2, 10, 10, 1, 27, 2}, {"conv2/3, rows 1 apart", 32, 2, 10, 10, 1, 27, 1},
+        {"conv4 (16 B, dilation 2, 12-voxel rows, rows 4 apart)", 16, 1, 12, 12, 2, 27, 4}, {"conv4, rows 2 apart", 16, 1, 12, 12, 2, 27, 2}, {"conv4, rows 1 apart", 16, 1, 12, 12, 2, 27, 1},
+        {"2-D f16x3 (32 B, 2 groups, rows 2 apart)", 32, 2, 10, 10, 1, 9, 2}, {"2-D f16x3, rows 1 apart", 32, 2, 10, 10, 1, 9, 1},
+    };
+    for (const Cfg &c : cfgs) {
+        const int G = c.ntap * c.cs8, nch = (G + 3) / 4;
+        double sum = 0, worst = 0;
+        for (int ch = 0; ch < nch; ++ch) {
+            auto h = pat([&](int l) {
+                const int v = l & 15, kq = l >> 4;
+                int g = 4 * ch + kq; if (g >= G) g = G - 1;
+                const int tap = g / c.cs8, cg = g % c.cs8;
+                const int dz = tap % 3, dy = (tap / 3) % 3, dx = c.ntap == 27 ? tap / 9 : 0;
+                const int off = (((dx * c.dil) * c.hy + dy * c.dil) * c.hz + dz * c.dil) * c.vs + cg * 16;
+                return (unsigned)((((v >> 3) * c.gap) * c.hz + (v & 7)) * c.vs + off);
+            });
+            const double t = run<128>(h, 8);
+            sum += t; worst = t > worst ? t : worst;
+        }
+        printf("8 waves, %-56s: mean %.1f  worst chunk %.1f clk/read over %d chunks\n", c.name, sum / nch, worst, nch);
+    }
     // PMAP (EPI_SIDEPOOL) fragment: rows adjacent
     {
         auto h = pat([](int l) { int v = l & 15, kq = l >> 4; return (unsigned)(((v >> 3) * 10 + (v & 7)) * 16 + kq * 1600); });
