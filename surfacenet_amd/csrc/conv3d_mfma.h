@@ -85,6 +85,9 @@
 #ifndef SN_ROWGAP_3x3
 #define SN_ROWGAP_3x3 4
 #endif
+#ifndef SN_PMAP_GAP4
+#define SN_PMAP_GAP4 1
+#endif
 #ifndef SN_ROWGAP_2D
 #define SN_ROWGAP_2D 4   // 2-D nets (32 bytes per halo pixel, 10-pixel rows, two channel groups per pass): a fragment's rows 4 apart = 1,280 bytes = 256 mod 512:
                          // the 32 lanes of an LDS pass then cover 512 distinct bytes (lds_probe: 37 vs 67 clocks per read under load)
@@ -477,6 +480,7 @@ conv3d_f16_mfma(ConvArgs a)
     static_assert(!PMAP || (MF == 4 && NW_ == 8 && K2D == 0), "EPI_SIDEPOOL: 8 waves x 4 fragments over an 8x8x8 tile");
     auto frag_xyz = [&](int m, int &hx, int &hy, int &hz) {
         if constexpr (C::F4) { hx = wave * MF + m; hy = v >> 2; hz = v & 3; }
+        else if constexpr (PMAP && SN_PMAP_GAP4) { hx = 2 * (wave & 3) + (m >> 1); hy = 2 * (wave >> 2) + (m & 1) + 4 * (v >> 3); hz = v & 7; }
         else if constexpr (PMAP) { hx = 2 * (wave & 3) + (m >> 1); hy = 4 * (wave >> 2) + 2 * (m & 1) + (v >> 3); hz = v & 7; }
         else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 4) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
         else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 2) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
@@ -1120,12 +1124,14 @@ conv3d_f16_mfma(ConvArgs a)
             }
             // ---- 2x2x2 max-pool in registers: x partner = fragment mm+2, y partner = lane ^ 8, z partner = lane ^ 1; stored in the layer's
             // own format (max(split(y)) == split(max(y)): the hi/lo rounding is monotone, so this equals pooling the stored tensor)
+            // SN_PMAP_GAP4: a fragment's rows lie 4 apart (conflict-free LDS reads, lds_probe): wave w owns rows {k, k+1, k+4, k+5}, k = 2 (w >> 2);
+            // the y partner is the same lane of fragment m ^ 1, so all four fragments of the wave collapse into ONE pooled value per lane pair
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
+            for (int mm = 0; mm < (SN_PMAP_GAP4 ? 1 : 2); ++mm) {
                 int hx, hy, hz;
                 frag_xyz(mm, hx, hy, hz);
                 const int gx = x0 + hx, gy = y0 + hy, gz = z0 + hz;
-                const bool writer = !(v & 1) && !(v & 8) && gx < DX && gy < D && gz < D;     // D even: the whole cell is inside
+                const bool writer = !(v & 1) && (SN_PMAP_GAP4 || !(v & 8)) && gx < DX && gy < D && gz < D;     // D even: the whole cell is inside
                 const size_t vlin = ((size_t)(gx >> 1) * Do + (gy >> 1)) * Do + (gz >> 1);
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
@@ -1134,7 +1140,8 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float t = fmaxf(y[mm][n][r], y[mm + 2][n][r]);
-                        t = fmaxf(t, __shfl_xor(t, 8));
+                        if constexpr (SN_PMAP_GAP4) t = fmaxf(t, fmaxf(y[1][n][r], y[3][n][r]));
+                        else t = fmaxf(t, __shfl_xor(t, 8));
                         t = fmaxf(t, __shfl_xor(t, 1));
                         if constexpr (SPLIT == 1) {
                             _Float16 hh, ll;
