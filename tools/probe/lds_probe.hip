@@ -133,6 +133,10 @@ int main()
         }
         printf("8 waves, %-56s: mean %.1f  worst chunk %.1f clk/read over %d chunks\n", c.name, sum / nch, worst, nch);
     }
+    // which tap pairs may share an LDS pass (16-byte voxels, rows 4 apart)? quarters (0,1) and (2,3) each d bytes apart
+    for (int d : {16, 32, 144, 160, 176, 320, 1280, 1440, 1600, 1616, 1760, 1920, 2880, 3040, 3200, 3360, 3520})
+        printf("8 waves: tap pair %4d B apart : %.1f clk/read\n", d,
+               run<128>(pat([d](int l) { int v = l & 15, kq = l >> 4; return (unsigned)((v >> 3) * 640 + (v & 7) * 16 + (kq & 1) * d + (kq >> 1) * 16384); }), 8));
     // PMAP (EPI_SIDEPOOL) fragment: rows adjacent
     {
         auto h = pat([](int l) { int v = l & 15, kq = l >> 4; return (unsigned)(((v >> 3) * 10 + (v & 7)) * 16 + kq * 1600); });
