@@ -109,6 +109,7 @@ struct sn_ctx {
     std::vector<float> simil_host;   // the 13 conv layers' fp32 parameters, kept to re-pack on a precision switch
     std::vector<sn_param_desc> simil_descs;
     void *sws = nullptr; size_t sws_bytes = 0; int sws_n = 0, sws_split = -1;
+    void *sview = nullptr; size_t sview_bytes = 0;      // sn_crop_embed: centres and embeddings of one whole call (no per-chunk host round trip)
     // post-pass (ray pooling / dense2sparse) workspace
     unsigned *d_num = nullptr;    // numeric status word: bit i = conv layer i of the launch order stored a non-finite / fp16-overflowing value
     std::vector<std::string> num_names;   // layer name of each status bit

@@ -259,17 +259,32 @@ extern "C" int sn_crop_embed(sn_ctx *c, int view, int n, const double *center_h,
     int rc;
     if ((rc = check_view(c, view)) != SN_OK) return rc;
     if ((rc = simil_ready(c)) != SN_OK) return rc;
+    // centres up and embeddings down ONCE per call: the chunks of a view (62 for a DTU image) run back to back on the stream instead of
+    // each waiting for two uploads, a download and a host synchronisation (7 % of the early-rejection stage)
+    const size_t need = (size_t)n * (2 * sizeof(double) + kEmb * sizeof(float)) + 256;
+    if (c->sview_bytes < need) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->sview) dev_free_owned(c, c->sview);
+        c->sview = nullptr; c->sview_bytes = 0;
+        unsigned char *p = nullptr;
+        const size_t cap = need + need / 4;
+        if ((rc = dev_alloc(c, &p, cap)) != SN_OK) return rc;
+        c->sview = p; c->sview_bytes = cap;
+    }
+    double *d_ch = static_cast<double *>(c->sview), *d_cw = d_ch + n;
+    float *d_emb = reinterpret_cast<float *>(d_cw + n);
+    HIPCHK(hipMemcpyAsync(d_ch, center_h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_cw, center_w, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     SimilWs w;
     for (int i0 = 0; i0 < n; i0 += kSimChunk) {
         const int m = std::min(kSimChunk, n - i0);
         if ((rc = simil_workspace(c, m, &w)) != SN_OK) return rc;
-        HIPCHK(hipMemcpyAsync(w.centers, center_h + i0, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(w.centers + c->sws_n, center_w + i0, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        if ((rc = launch_crop(c, view, m, w.centers, w.centers + c->sws_n, nullptr, w.p0, mean_bgr)) != SN_OK) return rc;
+        w.emb = d_emb + (size_t)i0 * kEmb;                       // the embedding kernels of this chunk write straight into the call's buffer
+        if ((rc = launch_crop(c, view, m, d_ch + i0, d_cw + i0, nullptr, w.p0, mean_bgr)) != SN_OK) return rc;
         if ((rc = run_simil(c, w, m)) != SN_OK) return rc;
-        HIPCHK(hipMemcpyAsync(embeddings + (size_t)i0 * kEmb, w.emb, sizeof(float) * kEmb * m, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
     }
+    HIPCHK(hipMemcpyAsync(embeddings, d_emb, sizeof(float) * kEmb * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return SN_OK;
 }
 
