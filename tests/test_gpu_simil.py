@@ -132,3 +132,26 @@ def test_early_rejection_dropin_fused_equals_three_step_protocol(sn):
     with pytest.raises(NotImplementedError):
         similarityNet.similarityNet_inference(None, (32, 32), param_values=values)
     runtime.reset()
+
+
+def test_crop_embed_many_chunks_equals_crop_then_embed(sn):
+    """sn_crop_embed over several internal chunks (centres up / embeddings down once per call, the call's buffer grown on demand) against
+    the two-step path: crop the same patches, preprocess on the host, embed them - row for row, and again after a smaller call."""
+    from surfacenet_amd import weights
+    values = weights.synthetic_simil_param_values(3)
+    imgs = scene_images()
+    H, W = imgs[0].shape[:2]
+    rs = np.random.RandomState(11)
+    n = 2 * 2040 + 17
+    ch = rs.uniform(-20, H + 20, n)                     # some centres outside the image: the crop clamps
+    cw = rs.uniform(-20, W + 20, n)
+    with sn.Context(cube_D=8, max_samples=2) as ctx:
+        ctx.set_images(imgs)
+        ctx.load_simil_param_values(values)
+        small = ctx.crop_embed(0, ch[:5], cw[:5], MEAN_BGR)                  # allocates the per-call buffer small ...
+        got = ctx.crop_embed(0, ch, cw, MEAN_BGR)                            # ... then has to grow it
+        raw = ctx.crop_patches(0, ch, cw)
+        want = ctx.patch2embedding(simil_oracle.preprocess(raw, MEAN_BGR))
+        again = ctx.crop_embed(0, ch[100:2200], cw[100:2200], MEAN_BGR)
+    assert got.shape == (n, 128) and np.array_equal(got, want)
+    assert np.array_equal(small, got[:5]) and np.array_equal(again, got[100:2200])
