@@ -14,6 +14,12 @@ What is modelled (surfacenet_amd/csrc/mx_format.h, conv3d_mfma.h, sn_api.hip pac
     weight block (one output channel x 8 input channels x two consecutive K groups: tap pairs (0,1), (2,3) .. for the 3x3x3 layers,
     channel-group pairs inside a 5-group slab for the 1x1x1 layers);
   * product "x3": exact on the stored values (the device drops lo*lo, 2^-22 relative, and accumulates in fp32).
+How close can device and model be? Stored tensors were compared directly (sn_debug_tensor, round 2, s=16): the concat buffer's fp16 plane
+differs from the model's in 0.24 % of its elements (fp32 vs fp64 upstream: one-ulp flips) and its lo codes in 2.7 %; a flipped (hi, lo)
+pair still represents the same value to 2^-15, which is also the size of the 6-bit quantisation error - so merge_conv_a's output, computed
+from those codes, already differs in 2.9 % of its fp16 values and 11 % of its lo codes. The final difference device - model (rms 0.5 of
+the device's error, correlation 0.82 between the two error fields) is this sensitivity, not a modelling gap: every parameter variant
+tried (premultipliers, lo exponent, block shape, renormalisation on / off) lowers the correlation.
 mode "f16x3" (the default): everything "x3" except the concat buffer and merge_conv_a's output (storage m6, premultipliers s = 2 / 0)
 and merge_conv_a / merge_conv_b (product m6); conv1_3 / conv2_3 feed their side conv and pool from unrounded registers.
 mode "f16m8": every tensor m6, every conv product m6 (the network input with s = -5)."""

@@ -1144,6 +1144,19 @@ int sn_memcpy_d2h_after(sn_ctx *c, int slot, void *dst, const void *src, size_t 
     return SN_OK;
 }
 
+// Test hook (not part of the ABI header): raw copy of an internal activation buffer ("cat": concat buffer, "ma": merge_conv_a output;
+// both planes, layout of DESIGN.md section 3) for comparing the device's stored codes with oracle/net_emulation.py.
+int sn_debug_tensor(sn_ctx *c, const char *name, void *host, size_t bytes)
+{
+    if (!c || !name || !host) return fail(SN_ERR_ARG, "null argument");
+    const _Float16 *p = !strcmp(name, "cat") ? c->cat : (!strcmp(name, "ma") ? c->ma : nullptr);
+    if (!p) return fail(SN_ERR_ARG, "unknown tensor %s", name);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost));
+    return SN_OK;
+}
+
 // Test hook (not part of the ABI header): the host-side 6-bit encoder the weight packer uses, so that a CPU test can pin it against the
 // format's decode table (tests/test_abi.py) - the device side of the format is pinned by tools/probe/fp6_probe.hip.
 int sn_debug_mx6_encode(float v, int fmt) { return (fmt == 2 || fmt == 3) ? (int)mx6_encode(v, fmt) : -1; }
