@@ -106,6 +106,18 @@
 #define SN_TIMING 0       // diagnostic build: per-wave shader-clock totals (whole kernel, vmcnt wait, barrier wait) added into a.status[1..] (results stay valid);
                           // 3..6 (f16m8 kernels): the two wait slots hold segment times of a weight piece instead, see the piece loop
 #endif
+#ifndef SN_PP
+#define SN_PP 0           // 1: ping-pong K loop for the f16m8 3x3x3 kernels (merge_conv_a / merge_conv_b), see the slab loop
+#endif
+#ifndef SN_PP_MERGE
+#define SN_PP_MERGE 0     // ping-pong: the two f16 chunks of a weight piece form ONE segment (2 * MF * NF MFMAs per burst, one barrier pair less per piece)
+#endif
+#ifndef SN_PP_WPRE
+#define SN_PP_WPRE 0      // ping-pong: the MX step's weight fragments are read in the load segments of the f16 chunks (1: all with the second, 2: split)
+#endif
+#ifndef SN_PP_B128
+#define SN_PP_B128 0      // ping-pong MX segment: read the activation code slots whole (ds_read_b128) instead of their 12 code bytes (ds_read_b96)
+#endif
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
 #endif
@@ -377,6 +389,7 @@ conv3d_f16_mfma(ConvArgs a)
     // Preconditions (checked by launch_conv): only the first / last tile along an axis has out-of-volume halo voxels, and the
     // slab fits the offset field. The one-plane f16 mode of the 2-D nets (4-group slabs: up to 400 MB) keeps the generic path.
     constexpr bool BUFH = (K2D == 0) || (SPLIT != 0);
+    constexpr bool PP = SN_PP && SPLIT == 2 && K2D == 0 && NW_ == 8 && KS == 3 && SN_MX_FMT != 0;   // ping-pong K loop (slab loop)
     constexpr unsigned FB_YLO = K2D ? (1u << 31) : HB_YLO, FB_YHI = K2D ? (1u << 30) : HB_YHI, FB_ZLO = K2D ? (1u << 29) : HB_ZLO,
                        FB_ZHI = K2D ? (1u << 28) : HB_ZHI, FB_NEVER = K2D ? 0x0FFFFFF0u : HB_ALWAYS, FB_OFFMASK = K2D ? 0x0FFFFFFFu : HB_OFFMASK;
     unsigned hword[HT];
@@ -422,6 +435,10 @@ conv3d_f16_mfma(ConvArgs a)
     auto stage_halo_buf = [&](int b, unsigned keep, int toff, int c0, int c8n, int xb) -> int {
         // opaque to the optimiser: otherwise it hoists (hword[k] & keep) + toff and the descriptors of BOTH candidate tiles out of the
         // K loop as loop invariants (8 VGPRs + 16 SGPRs live across it) and the accumulators spill
+        if constexpr (PP) {      // (wave-uniform values that hipcc's divergence analysis loses inside the ping-pong piece loop)
+            b = __builtin_amdgcn_readfirstlane(b); keep = __builtin_amdgcn_readfirstlane(keep);
+            toff = __builtin_amdgcn_readfirstlane(toff); c0 = __builtin_amdgcn_readfirstlane(c0);
+        }
         asm volatile("" : "+s"(b), "+s"(keep), "+s"(toff), "+s"(c0));
         const char *base0;
         int nrec;
@@ -431,6 +448,12 @@ conv3d_f16_mfma(ConvArgs a)
         } else {      // b = x0: the descriptor begins at the tile's first image inside group plane c0 and ends with group plane c0+c8n-1
             base0 = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)c0 * VOL * 8 + (size_t)b * D * D * 8);
             nrec = (c8n * (int)VOL - b * D * D) * 16;
+        }
+        if constexpr (PP) {      // ... and of the descriptor itself: a buffer_load with a "divergent" resource becomes a waterfall loop
+            const unsigned long long bq = (unsigned long long)(size_t)base0;
+            base0 = (const char *)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bq >> 32)) << 32) |
+                                           (unsigned)__builtin_amdgcn_readfirstlane((int)bq));
+            nrec = __builtin_amdgcn_readfirstlane(nrec);
         }
         int issued = 0;
         static_for<0, HT>([&](auto kc) {
@@ -449,10 +472,10 @@ conv3d_f16_mfma(ConvArgs a)
     // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n; raw s_barrier (a __syncthreads() would make hipcc drain
     // vmcnt(0) because LDS-DMAs are pending, defeating the counted wait)
     auto wg_barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
-    auto write_koff = [&](int c8n, int kb) {
+    auto write_koff_part = [&](int c8n, int kb, int t0, int nt) {
         const int G = C::NTAP * c8n, nchunk = (G + 3) >> 2;
         int *k = kbuf + kb * C::KOFF_N;
-        for (int g = tid; g < (nchunk + 4) * 4; g += C::NT) {
+        for (int g = t0; g < (nchunk + 4) * 4; g += nt) {
             int o = 0;
             if (g < G) {
                 const int tap = g / c8n, c8 = g - tap * c8n;
@@ -462,6 +485,7 @@ conv3d_f16_mfma(ConvArgs a)
             k[g] = o;
         }
     };
+    auto write_koff = [&](int c8n, int kb) { write_koff_part(c8n, kb, tid, C::NT); };
     // LDS-DMA of `nch` K-chunks of packed weights starting at byte offset `off` of this split's stream
     auto stage_w = [&](size_t off, int nch, int wbi) {
         const int cnt = nch * NF * NPL;
@@ -528,12 +552,13 @@ conv3d_f16_mfma(ConvArgs a)
         stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         wg_barrier();
+        if constexpr (PP) { if (wave >= C::NW / 2) wg_barrier(); }    // group 1 runs one barrier (= one segment slot) behind group 0
     }
 #if SN_STATIC_PRIO
     // static priority for the younger half of an 8-wave workgroup (MI355X_MICROARCH.md, two waves per SIMD): waves 4-7 lose
     // the VALU arbitration to waves 0-3 on every segment otherwise
     // (r2z A/B with the deferred barrier: merge_conv_a/b -1.2 %, conv4_x 0, conv1_x / conv2_x +1..3 % -> only where a wave owns >= 7 cout fragments)
-    if (C::NW == 8 && SPLIT != 0 && K2D == 0 && (NF >= 7 || DIL == 2) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+    if (!PP && C::NW == 8 && SPLIT != 0 && K2D == 0 && (NF >= 7 || DIL == 2) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
     int xb = 0;     // halo / tap-table buffer holding the current slab
     int wbi = 0;    // weight buffer holding the current piece
@@ -579,13 +604,242 @@ conv3d_f16_mfma(ConvArgs a)
             const int nc0 = last_slab ? 0 : c0 + c8n;
             const int wchunk = wchunks_of(c8n);
             const size_t nwoff = last_slab ? 0 : woff + (size_t)wchunk * NF * C::FRAG;
-            if (have_next) write_koff(nc8n, xb ^ 1);
+            if constexpr (!PP) { if (have_next) write_koff(nc8n, xb ^ 1); }
             // the next halo tile is fetched in npiece-1 instalments, each issued right after a weight piece so that a
             // counted vmcnt can wait for the weights while the newest halo DMAs stay in flight
             // Instalment size HQ is a compile-time constant (sized for a full slab) so that the wait in front of the barrier is a
             // fixed s_waitcnt vmcnt(HQ) or vmcnt(0), one scalar branch; the last instalment of a short slab takes whatever is left.
             int hdone = 0;
 
+            if constexpr (PP) {
+                // ---- PING-PONG K loop (round 3) ------------------------------------------------------------------
+                // The two waves of a SIMD (wave w of group 0 = waves 0..3 and wave w + 4 of group 1) never compete for the matrix pipe: a
+                // SEGMENT (one K-chunk of f16 MFMAs, or one MX step) is LOADED - every operand fragment of the segment read from LDS into
+                // registers, plus this wave's share of the DMA issue - and then COMPUTED as one uninterrupted burst of MF*NF MFMAs whose operands are
+                // all in registers; a workgroup barrier separates the two, and group 1 runs exactly one barrier behind group 0, so on every SIMD
+                // one wave computes while its partner loads. Nothing is software-pipelined inside a wave: the latency of the LDS reads, the
+                // address arithmetic, the DMA issue, the register shuffles of the 6-bit operands all sit in the load segment, which is shorter
+                // than the partner's compute burst. Buffer recycling needs no barrier of its own: the last reader of a weight piece / halo
+                // buffer (group 1, loading the piece's last segment) has waited for its reads before the barrier that precedes the first
+                // load slot of the next piece, where the refill DMAs are issued.
+                static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_FMT != 0 && SN_MX_B128 && BUFH, "ping-pong loop: f16m8 kernels with 6-bit MX operands");
+                const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
+                const unsigned k2_a = koff_a + kq * 4;
+                const unsigned xslab = xbuf_a + xb * C::XBUF;       // (wave-uniform; the per-lane fragment offsets xbase[] stay the only address registers)
+                int koA, koB;          // tap offsets of this lane quarter's group in f16 chunks 2p, 2p+1
+                long long k2;          // ... of its two groups 8p + 2kq, + 1 in the MX step
+                lds_read32<0>(koA, koff_a);
+                lds_read32<16>(koB, koff_a);
+                lds_read64<0>(k2, k2_a);
+                lgkm_wait<0>();
+                constexpr int WCNT = C::PCH * NF * NPL;                     // 1 KiB DMAs per weight piece
+                constexpr int WPW = (WCNT + C::NW - 1) / C::NW;             // ... per wave
+                auto stage_w_part = [&](size_t off, int wb, int k0, int k1) {
+                    const char *src = wsrc0 + off;
+                    char *dst = wbuf + wb * C::WBUF;
+                    for (int k = k0; k < k1; ++k) {
+                        const int i = k * C::NW + wave;
+                        if (i < WCNT) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
+                    }
+                };
+                int p = 0;
+                do {                                     // (do-while: a possible zero-trip path made hipcc spill 88 accumulator registers around the loop)
+                    const int ch0 = p * C::PCH;
+                    const unsigned wp = wbuf_a + wbi * C::WBUF;
+                    // the piece after this one: next piece of the slab, else the first piece of the next slab / tile
+                    const bool w_next = (p + 1 < npiece) || have_next;
+                    const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
+                    const bool has_B = ch0 + 1 < nchunk;             // (the last piece of a slab with an odd chunk count has no second f16 chunk)
+                    int hnow = 0;
+                    // SN_TIMING (diagnostic builds): shader-clock stamps 0 segment start | 1 operands landed | 2 barrier released | 3 MFMAs issued | 4 barrier released;
+                    // odd values accumulate {load 0-1, wait 1-2}, even {compute 2-3, wait 3-4}; 1/2 all segments, 3/4 MX segments only, 5/6 f16 segments only
+                    long long ppt[5] = {0, 0, 0, 0, 0};
+#define PP_T(i) do { if constexpr (SN_TIMING) { ppt[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
+                    auto pp_account = [&](bool mx) {
+                        if constexpr (SN_TIMING) {
+                            if ((SN_TIMING <= 2) || ((SN_TIMING <= 4) == mx)) {
+                                if (SN_TIMING & 1) { t_vm += ppt[1] - ppt[0]; t_bar += ppt[2] - ppt[1]; }
+                                else { t_vm += ppt[3] - ppt[2]; t_bar += ppt[4] - ppt[3]; }
+                                ++n_piece;
+                            }
+                        }
+                    };
+                    half8 xf[2][MF], wf[2][NF];                     // operands of the f16 chunks 2p, 2p+1
+                    constexpr int mxo = 2 * NF * 1024;
+                    v4i wa4[NF];                                    // MX step: a lane's 192-bit weight operand = 128 + 64 bits ...
+                    long long wb2[NF], wsc;                         // ... and the E8M0 block scales of its NF fragments
+                    typedef int v2i_ __attribute__((ext_vector_type(2)));
+                    auto load_f16 = [&](auto ccc, int ko) {
+                        constexpr int cc = decltype(ccc)::value;
+                        const unsigned kos = xslab + (unsigned)ko;
+                        static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<0>(xf[cc][m], (unsigned)xbase[m] + kos); });
+                        static_for<0, NF>([&](auto nc) { constexpr int n = decltype(nc)::value; lds_read128<(cc * NF + n) * 1024>(wf[cc][n], wp); });
+                    };
+                    auto load_mxw = [&](auto n0c, auto n1c) {        // MX weight fragments [n0, n1) (and the scales with fragment 0)
+                        constexpr int n0 = decltype(n0c)::value, n1 = decltype(n1c)::value;
+                        if constexpr (n0 == 0 && n1 > 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
+                        static_for<n0, n1>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            lds_read128i<mxo + n * 2048>(wa4[n], wp);
+                            lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
+                        });
+                    };
+                    auto compute_f16 = [&](auto ccc) {
+                        constexpr int cc = decltype(ccc)::value;
+#pragma unroll
+                        for (int n = 0; n < NF; ++n)
+#pragma unroll
+                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);
+                    };
+                    using I0 = std::integral_constant<int, 0>;
+                    using I1 = std::integral_constant<int, 1>;
+                    // MX weight fragments read ahead, in the load segments of the f16 chunks: SN_PP_WPRE 0 none | 1 all with chunk 2p+1 (or the merged
+                    // segment) | 2 NFA with chunk 2p, the rest with chunk 2p+1
+                    constexpr int NFA = SN_PP_WPRE == 2 ? (NF + 1) / 2 : 0, NFB = SN_PP_WPRE ? NF : 0;
+                    using INFA = std::integral_constant<int, NFA>;
+                    using INFB = std::integral_constant<int, NFB>;
+                    using INF = std::integral_constant<int, NF>;
+                    if constexpr (SN_PP_MERGE) {
+                        // ---- segment F: both f16 chunks of the piece, 2 * MF * NF MFMAs in one burst; DMA: the next weight piece; tap table of the next slab
+                        PP_T(0);
+                        load_f16(I0{}, koA);
+                        if (has_B) load_f16(I1{}, koB);
+                        load_mxw(I0{}, INFB{});
+                        if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WPW);
+                        if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                        lgkm_wait<0>();
+                        PP_T(1);
+                        wg_barrier();
+                        PP_T(2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute_f16(I0{});
+                        if (has_B) compute_f16(I1{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_T(3);
+                        wg_barrier();
+                        PP_T(4);
+                        pp_account(false);
+                    } else {
+                        // ---- segment A: f16 chunk 2p; DMA: first half of the next weight piece; group 0 also writes the next slab's tap table
+                        PP_T(0);
+                        load_f16(I0{}, koA);
+                        load_mxw(I0{}, INFA{});
+                        if (w_next) stage_w_part(w_off, wbi ^ 1, 0, (WPW + 1) / 2);
+                        if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                        lgkm_wait<0>();
+                        PP_T(1);
+                        wg_barrier();
+                        PP_T(2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute_f16(I0{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_T(3);
+                        wg_barrier();
+                        PP_T(4);
+                        pp_account(false);
+                        // ---- segment B: f16 chunk 2p+1; DMA: second half
+                        if (has_B) {
+                            PP_T(0);
+                            load_f16(I1{}, koB);
+                            load_mxw(INFA{}, INFB{});
+                            if (w_next) stage_w_part(w_off, wbi ^ 1, (WPW + 1) / 2, WPW);
+                            lgkm_wait<0>();
+                            PP_T(1);
+                            wg_barrier();
+                            PP_T(2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            compute_f16(I1{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            PP_T(3);
+                            wg_barrier();
+                            PP_T(4);
+                            pp_account(false);
+                        } else {
+                            if (w_next) stage_w_part(w_off, wbi ^ 1, (WPW + 1) / 2, WPW);
+                        }
+                    }
+                    // ---- segment M: the MX step of the piece's 64 k; DMA: the next slab's halo tile (first piece of a slab); waits for the weights
+                    {
+                        PP_T(0);
+                        v3i x6[MF][2];
+                        v4i x8h[MF][2];                                       // SN_PP_B128: whole slots (4 LDS cycles per read instead of 8; the pad dword is dropped below)
+                        int koAn = 0, koBn = 0;
+                        long long k2n = 0;
+                        const unsigned ks0 = xslab + C::XPLANE + (unsigned)(int)k2, ks1 = xslab + C::XPLANE + (unsigned)(int)(k2 >> 32);
+                        static_for<0, MF>([&](auto mc) {
+                            constexpr int m = decltype(mc)::value;
+                            if constexpr (SN_PP_B128) {
+                                lds_read128i<0>(x8h[m][0], (unsigned)xbase[m] + ks0);
+                                lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
+                            } else {
+                                lds_read96i<0>(x6[m][0], (unsigned)xbase[m] + ks0);
+                                lds_read96i<0>(x6[m][1], (unsigned)xbase[m] + ks1);
+                            }
+                        });
+                        if (!(SN_PP_WPRE && (SN_PP_MERGE || has_B))) {
+                            if constexpr (SN_PP_WPRE == 0 || SN_PP_MERGE) load_mxw(I0{}, INF{});
+                            else load_mxw(INFA{}, INF{});                  // (no chunk 2p+1 in this piece: its share of the fragments is read here)
+                        }
+                        if (p + 1 < npiece) {
+                            lds_read32<0>(koAn, koff_a + (unsigned)(ch0 + 2) * 16);
+                            lds_read32<0>(koBn, koff_a + (unsigned)(ch0 + 3) * 16);
+                            lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
+                        }
+#ifndef SN_PP_NOHALO
+                        if (p == 0 && have_next && !(SN_ABL & 1))
+#else
+                        if (0)
+#endif
+                            hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                        // the next weight piece (issued two load slots ago) has landed; this slab's halo DMAs, just issued, may still fly
+                        if (p + 1 < npiece && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
+                        else if (p + 1 < npiece && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lgkm_wait<0>();
+                        v8i x8[MF], wa[NF];
+#pragma unroll
+                        for (int m = 0; m < MF; ++m) {
+                            if constexpr (SN_PP_B128) {
+                                asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
+                                x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
+                            } else {
+                                asm volatile("" : "+v"(x6[m][0]), "+v"(x6[m][1]));
+                                x8[m] = __builtin_shufflevector(x6[m][0], x6[m][1], 0, 1, 2, 3, 4, 5, -1, -1);
+                            }
+                        }
+#pragma unroll
+                        for (int n = 0; n < NF; ++n) {
+                            const v2i_ b2 = __builtin_bit_cast(v2i_, wb2[n]);
+                            const v4i b4 = __builtin_shufflevector(b2, b2, 0, 1, -1, -1);
+                            wa[n] = __builtin_shufflevector(wa4[n], b4, 0, 1, 2, 3, 4, 5, -1, -1);
+                        }
+                        if (p + 1 < npiece) { koA = koAn; koB = koBn; k2 = k2n; }
+                        // (pins the operand tuples - and the 3 register moves per activation fragment that forming them costs - in front of the barrier,
+                        // i.e. into the load segment: instruction selection otherwise sinks them to their first use, the head of the MFMA burst)
+#pragma unroll
+                        for (int m = 0; m < MF; ++m) asm volatile("" : "+v"(x8[m]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_T(1);
+                        wg_barrier();
+                        PP_T(2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        static_for<0, NF>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
+#pragma unroll
+                            for (int m = 0; m < MF; ++m)
+                                acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_T(3);
+                        wg_barrier();
+                        PP_T(4);
+                        pp_account(true);
+                    }
+#undef PP_T
+                    wbi ^= 1;
+                } while (++p < npiece);
+            } else {
             // ---- software-pipelined K loop over this slab ----------------------------------------------------
             // Register stages: X fragments of chunk c+1 and the tap offset of chunk c+2 are fetched while chunk c
             // computes (the halo buffer is immutable for the whole slab, so this runs across the per-piece barrier);
@@ -935,6 +1189,7 @@ conv3d_f16_mfma(ConvArgs a)
                     }
                 }
                 wbi ^= 1;
+            }
             }
             xb ^= 1;
             c0 += c8n;
@@ -1288,6 +1543,7 @@ conv3d_f16_mfma(ConvArgs a)
             }
         }
     }
+    if constexpr (PP) { if (wave < C::NW / 2) wg_barrier(); }       // pairs with group 1's last compute segment
     if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, a.status_bit);
     if constexpr (SN_TIMING) {
         if (a.status && lane == 0) {        // [2..9]: per layer-bit slot of 4 x u64: kernel cycles, vmcnt-wait cycles, barrier-wait cycles, pieces (summed over waves)

@@ -3,6 +3,7 @@ cube origins inside the view frusta, and the overlapping cube grid a scene's bou
 from disk, so it travels to the GPU box as code.
 
     synthetic_scene   the 2-view workload of BASELINE configs[1] / SURVEY §8(d)
+    dataset_scene     calibration + cube grid of BASELINE configs[2] / [4] (DTU scan9, Middlebury dino) with synthetic views
     cube_grid         the cube table of utils/scene.py:7-61 (`initializeCubes`) — an INPUT CONTRACT of the hot path
                       (structured dtype xyz f32x3 | ijk u32x3 | resol f32, k fastest); checked row for row against
                       tables produced by the reference itself (tests/golden/scene_cases.npz, tests/test_host_logic.py)
@@ -58,3 +59,26 @@ def cube_grid(resol, cube_D, cube_Dcenter, cube_overlapping_ratio, BB):
     cubes["xyz"] = cubes["ijk"] * step + (BB[:, 0][None, :] - margin)
     cubes["resol"] = resol
     return cubes, side
+
+
+def dataset_scene(config, cube_D=32, max_cubes=0, n_vp=0):
+    """BASELINE configs[2] / configs[4] on their own calibration: all P matrices and the bounding box of DTU scan9 (49 views of
+    1200x1600, resol 0.4 mm, N_viewPairs4inference 5; params.py:165-172) or Middlebury dinoSparseRing (16 views of 480x640, resol
+    0.00025, 16 view pairs; params.py:176-182) from surfacenet_amd/data/calibration.npz (read by the reference's own readers in
+    oracle/gen_golden_scene.py), the reference's overlapping cube grid (`cube_grid`, overlap 1/2: params.py:114) and seeded noise views
+    (no dataset pixels on the GPU box). `max_cubes` > 0 takes an even sample of the grid.
+    Returns (P (V,3,4) f64, images list, cubes CUBE_DTYPE, cube_D_mm, cube_Dcenter, N_viewPairs4inference)."""
+    import os
+    cal = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "calibration.npz"))
+    Dc = {32: 26, 64: 52}.get(cube_D, cube_D - 4)                                                   # params.py:107
+    if config == "dtu_scan9":
+        P, hw, resol, BB, n_vp = cal["P_dtu49"], (1200, 1600), np.float32(0.4), cal["scan9_BB"], n_vp or 5
+    elif config == "dino":
+        P, hw, resol, BB, n_vp = cal["P_mid16"], (480, 640), np.float32(0.00025), cal["dino_BB"], n_vp or 16
+    else:
+        raise ValueError("config must be 'dtu_scan9' or 'dino'")
+    cubes, cube_D_mm = cube_grid(resol, cube_D, Dc, 1 / 2., BB)
+    if max_cubes:
+        cubes = cubes[np.linspace(0, len(cubes) - 1, min(int(max_cubes), len(cubes))).astype(np.int64)]
+    imgs = [synth_image(2000 + v, hw[0], hw[1]) for v in range(P.shape[0])]
+    return np.asarray(P, dtype=np.float64), imgs, cubes, cube_D_mm, Dc, n_vp

@@ -67,12 +67,28 @@ def validate(values):
     for (layer, p, shape), v in zip(PARAM_LAYOUT, values):
         if tuple(np.shape(v)) != tuple(shape):
             raise ValueError("%s.%s: expected shape %s, got %s" % (layer, p, shape, np.shape(v)))
+        # The four BatchNorm vectors of a layer have the same shape, so the shape check cannot tell them apart. Lasagne's BatchNormLayer
+        # registers beta, gamma, mean, inv_std in that order and inv_std = 1/sqrt(var + eps) is strictly positive and finite - the one
+        # property that distinguishes a slot: a file written in another order (e.g. mean and inv_std swapped) fails here, loudly.
+        if p == "inv_std" and not (np.all(np.isfinite(v)) and np.all(np.asarray(v) > 0)):
+            raise ValueError("%s.inv_std must be finite and > 0 (got min %g): the file's BatchNorm vectors are not in Lasagne's "
+                             "(beta, gamma, mean, inv_std) order" % (layer, float(np.min(v))))
+
+
+def _load_py2_pickle(path):
+    """A Python-2 pickle of a flat list of numpy arrays, protocol 0 (`pickle.dump(values, f)`, ASCII - what survives the reference's
+    text-mode `open(model_file)`, nets/SurfaceNet.py:398) or protocol 1 / 2: py2 `str` payloads need encoding='latin1' under Python 3,
+    and numpy turns the latin-1 text of an array's data string back into bytes."""
+    with open(path, "rb") as f:
+        values = pickle.load(f, encoding="latin1")
+    if not isinstance(values, (list, tuple)):
+        raise ValueError("%s: expected a pickled list of arrays (lasagne.layers.get_all_param_values), got %s" % (path, type(values).__name__))
+    return values
 
 
 def load_lasagne_pickle(path):
     """Reads the reference's `*.model` file: a Python-2 pickle of a flat list of numpy arrays."""
-    with open(path, "rb") as f:
-        values = pickle.load(f, encoding="latin1")
+    values = _load_py2_pickle(path)
     values = [np.asarray(v, dtype=np.float32) for v in values]
     validate(values)
     return values
@@ -167,8 +183,7 @@ def validate_simil(values):
 
 def load_simil_pickle(path):
     """The reference's similarityNet `*.model` file (nets/similarityNet.py:240-242): py2 pickle of a flat list of arrays."""
-    with open(path, "rb") as f:
-        values = pickle.load(f, encoding="latin1")
+    values = _load_py2_pickle(path)
     values = [np.asarray(v, dtype=np.float32) for v in values]
     validate_simil(values)
     return values

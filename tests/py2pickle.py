@@ -55,3 +55,50 @@ def dumps_py2(arrays):
     for a in arrays:
         out += _array(a, memo)
     return out + APPENDS + STOP
+
+
+# ---- protocol 0 (what `pickle.dump(values, f)` writes under Python 2 when no protocol is given; the reference re-opens the file in
+# TEXT mode, nets/SurfaceNet.py:398, which only an ASCII pickle survives on every platform) ---------------------------------------
+def _repr_py2_str(b):
+    """Python 2's repr() of a byte string: quote choice and escapes as stringobject.c:PyString_Repr."""
+    quote = b'"' if (b"'" in b and b'"' not in b) else b"'"
+    out = bytearray(quote)
+    q = quote[0]
+    for c in b:
+        if c == q or c == 0x5C:
+            out += b"\\" + bytes([c])
+        elif c == 0x09:
+            out += b"\\t"
+        elif c == 0x0A:
+            out += b"\\n"
+        elif c == 0x0D:
+            out += b"\\r"
+        elif c < 0x20 or c >= 0x7F:
+            out += b"\\x%02x" % c
+        else:
+            out.append(c)
+    return bytes(out + quote)
+
+
+def dumps_py2_proto0(arrays):
+    """bytes of pickle.dumps(list(arrays)) (protocol 0) under Python 2.7 / numpy 1.13: GLOBAL / MARK / INT / STRING / TUPLE / REDUCE /
+    BUILD / PUT / APPEND opcodes in their text forms, the array bytes as a repr()-escaped py2 `str`."""
+    n = [0]
+
+    def put():
+        i = n[0]
+        n[0] += 1
+        return b"p%d\n" % i
+
+    I = lambda v: b"I%d\n" % int(v)
+    S = lambda b: b"S" + _repr_py2_str(b) + b"\n"
+    out = b"(l" + put()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        descr = a.dtype.str.lstrip("<>|=").encode()
+        out += b"cnumpy.core.multiarray\n_reconstruct\n" + put() + b"(cnumpy\nndarray\n" + put() + b"(" + I(0) + b"t" + put() + S(b"b") + put() + b"t" + put() + b"R" + put()
+        out += b"(" + I(1) + b"(" + b"".join(I(d) for d in a.shape) + b"t" + put()
+        out += b"cnumpy\ndtype\n" + put() + b"(" + S(descr) + put() + I(0) + I(1) + b"t" + put() + b"R" + put()
+        out += b"(" + I(3) + S(b"<" if a.dtype.itemsize > 1 else b"|") + put() + b"NNN" + I(-1) + I(-1) + I(0) + b"t" + put() + b"b"
+        out += b"I00\n" + S(a.tobytes()) + put() + b"t" + put() + b"b" + b"a"
+    return out + b"."

@@ -146,3 +146,45 @@ def test_scene_cache_sees_in_place_changes_and_recycled_lists(dropin):
     b = CVC.gen_coloredCubes(models_img=imgs, **kw)
     inv = CVC.gen_coloredCubes(models_img=[255 - im for im in golden_util.case_images(c)], **kw)
     assert np.array_equal(b, inv) and not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("proto", [2, 0])
+def test_inference_entry_points_read_python2_model_files(dropin, tmp_path, proto):
+    """`SurfaceNet_inference(N_viewPairs4inference, model_file, layerNameList_2_load)` (nets/SurfaceNet.py:385-402) and
+    `similarityNet_inference(model_file, imgPatch_hw_size)` (nets/similarityNet.py:229-244) on `.model` FILES in the formats Python 2
+    writes them (cPickle protocol 2, and the ASCII protocol 0 that the reference's text-mode open implies; tests/py2pickle.py emits
+    both opcode by opcode): file -> pickle -> sn_load_weights / sn_simil_load_weights -> forward on the GPU, against the oracle run on the
+    arrays that went into the file."""
+    CVC, SurfaceNet, runtime = dropin
+    import py2pickle
+    import synth
+    from oracle import net_oracle, simil_oracle
+    from surfacenet_amd import similarityNet, weights
+    dumps = py2pickle.dumps_py2 if proto == 2 else py2pickle.dumps_py2_proto0
+    values = list(synth.calibrated_params(2))
+    model_file = tmp_path / "2D_2_3D-19-0.918_0.951.model"                    # params.py:106
+    model_file.write_bytes(dumps(values))
+    s, n, n_vp = 16, 2, 2
+    relw_fn, net_fn = SurfaceNet.SurfaceNet_inference(n_vp, str(model_file), ["output_SurfaceNet_reshape", "output_softmaxWeights"])
+    X = synth.random_cvc(n * n_vp, s, 77)
+    w = (np.random.RandomState(5).rand(n, n_vp) + 0.1).astype(np.float32)
+    fused, unfused = net_fn(X, w)
+    f64, u64 = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp)
+    e = max(float(np.abs(fused - f64).max()), float(np.abs(unfused - u64).max()))
+    print("protocol %d: SurfaceNet from file, L_inf vs fp64 oracle %.3e" % (proto, e))
+    assert e < 2e-4
+    feats = np.random.RandomState(6).randn(3 * 4, 258).astype(np.float32)
+    got = relw_fn(feats, n_samples_perGroup=4)                                 # the relative-weight MLP rides in the same file (arrays 98..104)
+    ref = net_oracle.relative_weights(feats, values, 4) if hasattr(net_oracle, "relative_weights") else None
+    assert got.shape == (3, 4) and np.allclose(got.sum(axis=1), 1, atol=1e-5)
+    if ref is not None:
+        assert np.abs(got - ref).max() < 1e-5
+    svals = weights.synthetic_simil_param_values(4)
+    simil_file = tmp_path / "epoch33_acc_tr0.707_val0.791.model"               # params.py:91
+    simil_file.write_bytes(dumps(svals))
+    p2e, pair_fn = similarityNet.similarityNet_inference(str(simil_file), (64, 64))
+    patches = (np.random.RandomState(8).randint(0, 256, (5, 3, 64, 64)).astype(np.float32) - np.asarray([103.939, 116.779, 123.68], np.float32)[None, :, None, None])
+    emb = p2e(patches)
+    ref_emb = simil_oracle.embedding_torch(patches, svals, dtype="float64")
+    print("protocol %d: similarityNet from file, embedding L_inf vs fp64 oracle %.3e" % (proto, float(np.abs(emb - ref_emb).max())))
+    assert emb.shape == (5, 128) and np.abs(emb - ref_emb).max() < 1e-4

@@ -109,6 +109,38 @@ def test_genuine_python2_pickle_weight_file(tmp_path):
     assert len(back) == 30 and all(np.array_equal(a, b) for a, b in zip(sv, back))
 
 
+def test_python2_protocol0_weight_file_and_bn_order_guard(tmp_path):
+    """The other format a Python-2 `pickle.dump(values, f)` writes - protocol 0, the ASCII form, the only one that survives the
+    reference's text-mode open (nets/SurfaceNet.py:398 `open(model_file)`) on every platform - with the array bytes as repr()-escaped
+    py2 strings; and the one check that can tell a layer's four same-shaped BatchNorm vectors apart: inv_std > 0."""
+    import py2pickle
+    vals = weights.synthetic_param_values(9)
+    blob = py2pickle.dumps_py2_proto0(vals)
+    assert blob[:3] == b"(lp" and b"cnumpy.core.multiarray\n_reconstruct" in blob and max(blob) < 0x80      # pure ASCII
+    with pytest.raises(UnicodeDecodeError):
+        pickle.loads(blob)
+    p = tmp_path / "proto0.model"
+    p.write_bytes(blob)
+    back = weights.load_lasagne_pickle(str(p))
+    assert len(back) == 105 and all(b.dtype == np.float32 and np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(vals, back))
+    sv = weights.synthetic_simil_param_values(3)
+    q = tmp_path / "simil_proto0.model"
+    q.write_bytes(py2pickle.dumps_py2_proto0(sv))
+    assert all(np.array_equal(a, b) for a, b in zip(sv, weights.load_simil_pickle(str(q))))
+    # a file whose BatchNorm vectors are in another order (mean <-> inv_std) has every shape right: the positivity of inv_std catches it
+    idx = {(l, n): i for i, (l, n, _) in enumerate(weights.PARAM_LAYOUT)}
+    swapped = list(vals)
+    i, j = idx[("conv2_2", "mean")], idx[("conv2_2", "inv_std")]
+    swapped[i], swapped[j] = swapped[j], swapped[i]
+    assert (swapped[j] < 0).any()
+    p.write_bytes(py2pickle.dumps_py2(swapped))
+    with pytest.raises(ValueError, match="inv_std"):
+        weights.load_lasagne_pickle(str(p))
+    p.write_bytes(py2pickle.dumps_py2({"not": "a list"}.keys() and [vals[0]]))
+    with pytest.raises(ValueError):
+        weights.load_lasagne_pickle(str(p))
+
+
 def test_interpolation_kernel_pinned_to_reference_W_5D():
     """The fixed stencil of Bilinear_3DInterpolation is the one CNN constant that can be pinned: oracle/gen_golden_w5d.py executed
     the reference's own `__W_5D__` (nets/layers.py:361-372) -> tests/golden/w5d_cases.npz. The product's weight-file entry, the

@@ -27,30 +27,21 @@ sys.path.insert(0, ROOT)
 
 def build_scene(a):
     from surfacenet_amd import synthetic
+    if a.config in ("dtu_scan9", "dino"):
+        return synthetic.dataset_scene(a.config, a.cube_d, a.max_cubes, a.n_vp)
     cal = np.load(os.path.join(ROOT, "surfacenet_amd", "data", "calibration.npz"))
     s = a.cube_d
     Dc = {32: 26, 64: 52}.get(s, s - 4)                                      # params.py:107
-    if a.config == "dtu_scan9":
-        P, hw, resol, BB = cal["P_dtu49"], (1200, 1600), np.float32(0.4), cal["scan9_BB"]          # params.py:166-172
-        n_vp = a.n_vp or 5                                                                           # params.py:165
-    elif a.config == "dino":
-        P, hw, resol, BB = cal["P_mid16"], (480, 640), np.float32(0.00025), cal["dino_BB"]         # params.py:177-181
-        n_vp = a.n_vp or 16                                                                          # BASELINE configs[4]: 16 view pairs
-    else:
-        P4 = cal["P_dtu49"][:4]
-        P = np.stack([np.array([[np.cos(0.01 * (v // 4)), -np.sin(0.01 * (v // 4)), 0], [np.sin(0.01 * (v // 4)), np.cos(0.01 * (v // 4)), 0],
-                                [0, 0, 1]]) @ P4[v % 4] for v in range(a.views)])
-        hw, resol, n_vp = (1200, 1600), np.float32(0.4), a.n_vp or 2
-        g = int(np.ceil(a.cubes ** (1 / 3.0)))
-        BB = None
-    if BB is not None:
-        cubes, cube_D_mm = synthetic.cube_grid(resol, s, Dc, 1 / 2., BB)                           # params.py:114 overlap 1/2
-    else:
-        ijk = np.indices((g, g, g)).reshape(3, -1).T[: a.cubes]
-        cubes = np.empty((a.cubes,), dtype=synthetic.CUBE_DTYPE)
-        cube_D_mm = resol * s
-        cubes["ijk"], cubes["resol"] = ijk, resol
-        cubes["xyz"] = (ijk * (cube_D_mm / 2) + np.array([-60.0, -60.0, 560.0])).astype(np.float32)
+    P4 = cal["P_dtu49"][:4]
+    P = np.stack([np.array([[np.cos(0.01 * (v // 4)), -np.sin(0.01 * (v // 4)), 0], [np.sin(0.01 * (v // 4)), np.cos(0.01 * (v // 4)), 0],
+                            [0, 0, 1]]) @ P4[v % 4] for v in range(a.views)])
+    hw, resol, n_vp = (1200, 1600), np.float32(0.4), a.n_vp or 2
+    g = int(np.ceil(a.cubes ** (1 / 3.0)))
+    ijk = np.indices((g, g, g)).reshape(3, -1).T[: a.cubes]
+    cubes = np.empty((a.cubes,), dtype=synthetic.CUBE_DTYPE)
+    cube_D_mm = resol * s
+    cubes["ijk"], cubes["resol"] = ijk, resol
+    cubes["xyz"] = (ijk * (cube_D_mm / 2) + np.array([-60.0, -60.0, 560.0])).astype(np.float32)
     if a.max_cubes:
         cubes = cubes[np.linspace(0, len(cubes) - 1, min(a.max_cubes, len(cubes))).astype(np.int64)]   # an even sample of the grid
     imgs = [synthetic.synth_image(2000 + v, hw[0], hw[1]) for v in range(P.shape[0])]

@@ -50,6 +50,8 @@ def main():
         lib.sn_debug_trace.restype = ctypes.c_int
         lib.sn_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.sn_debug_trace(ctx._h, tr.ctypes.data_as(ctypes.c_void_p))
+        if not tr.any():
+            return                                           # (builds without the per-piece trace, e.g. the ping-pong kernels)
         tr = tr[200:1800]                                   # steady state of workgroup 0 in merge_conv_b (EPI_FINAL)
         arr, rel = tr[:, :, 0], tr[:, :, 1]
         piece = np.diff(rel.max(axis=1)).astype(np.float64)                     # release-to-release = piece time
