@@ -26,6 +26,10 @@ extern "C" {
 
 #define SN_ABI_VERSION 1
 
+/* The library is built with -fvisibility=hidden: the functions below are its WHOLE dynamic symbol table
+ * (tests/test_abi.py compares `nm -D` with this header). */
+#define SN_API __attribute__((visibility("default")))
+
 typedef struct sn_ctx sn_ctx;
 
 enum sn_status {
@@ -50,11 +54,11 @@ typedef struct {
 /* cube_D = s of the s^3 colored voxel cube (params.py:65, 32 or 64; any multiple of 4 in [8,96]
  * except 36 and 68 is accepted); max_samples = largest n*n_vp processed per internal pass (activation
  * workspace is sized for it; larger calls are chunked). Returns NULL on failure (sn_last_error). */
-sn_ctx *sn_create(int device_id, int cube_D, int max_samples);
-void sn_destroy(sn_ctx *ctx);
-const char *sn_last_error(void);
-int sn_version(void);
-int sn_synchronize(sn_ctx *ctx);
+SN_API sn_ctx *sn_create(int device_id, int cube_D, int max_samples);
+SN_API void sn_destroy(sn_ctx *ctx);
+SN_API const char *sn_last_error(void);
+SN_API int sn_version(void);
+SN_API int sn_synchronize(sn_ctx *ctx);
 
 /* Arithmetic of the 3D-CNN (the CVC warp is always the reference's fp64/int arithmetic):
  *   SN_PRECISION_F16X3 (default): operands carried as hi+lo pairs of fp16 (22 significant bits), three
@@ -73,75 +77,75 @@ int sn_synchronize(sn_ctx *ctx);
  *       (v_mfma_scale_f32_16x16x128_f8f6f4); L_inf 1e-4 .. 4e-4 (bar 1e-3). */
 #define SN_PRECISION_F16M8 2
 #define SN_PRECISION_F16X3_PURE 3
-int sn_set_precision(sn_ctx *ctx, int mode);
-int sn_get_precision(sn_ctx *ctx);
+SN_API int sn_set_precision(sn_ctx *ctx, int mode);
+SN_API int sn_get_precision(sn_ctx *ctx);
 
 /* ---- one-time setup -------------------------------------------------------------------------- */
 /* Replaces lasagne.layers.set_all_param_values(...) in SurfaceNet_inference
  * (nets/SurfaceNet.py:385-402). `descs` lists the 105 arrays of the reference pickle in its order
  * (98 for the network alone: the relative-weight MLP arrays may be omitted). BN folding and the
  * fp16 MFMA-fragment packing happen inside. */
-int sn_load_weights(sn_ctx *ctx, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params);
+SN_API int sn_load_weights(sn_ctx *ctx, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params);
 /* models_img of CVC.gen_coloredCubes (utils/CVC.py:56): V images, (H[v], W[v], 3) uint8 RGB. */
-int sn_set_images(sn_ctx *ctx, int V, const uint8_t *const *imgs, const int *H, const int *W);
+SN_API int sn_set_images(sn_ctx *ctx, int V, const uint8_t *const *imgs, const int *H, const int *W);
 /* cameraPOs of CVC.gen_coloredCubes: (V,3,4) float64 row-major projection matrices. */
-int sn_set_cameras(sn_ctx *ctx, int V, const double *P);
+SN_API int sn_set_cameras(sn_ctx *ctx, int V, const double *P);
 
 /* ---- hot path, host buffers ------------------------------------------------------------------ */
 /* CVC.gen_coloredCubes (utils/CVC.py:56-104) [+ CVC.preprocess_augmentation, utils/CVC.py:108-111,
  * when mean6 != NULL]. view_pairs (n, n_vp, 2) int64 indices into the image/camera lists;
  * xyz (n,3) float32 cube min corners; resol (n,) float32; out (n*n_vp, 6, s,s,s) float32. */
-int sn_cvc(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
+SN_API int sn_cvc(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
            const float *mean6, float *out);
 /* nViewPair_SurfaceNet_fn (nets/SurfaceNet.py:365-382; call at main_reconstruct.py:145-146).
  * X (n*n_vp, 6, s,s,s) float32 mean-subtracted; w (n, n_vp) float32 (NULL iff n_vp == 1);
  * fused (n,1,s,s,s); unfused (n,n_vp,s,s,s) or NULL. */
-int sn_forward(sn_ctx *ctx, int n, int n_vp, const float *X, const float *w, float *fused, float *unfused);
+SN_API int sn_forward(sn_ctx *ctx, int n, int n_vp, const float *X, const float *w, float *fused, float *unfused);
 /* The loop body main_reconstruct.py:134-146 in one call: CVC warp -> mean subtraction -> CNN ->
  * fusion, nothing but the cube parameters crossing PCIe. cvc_out (optional) receives the
  * mean-subtracted CVC tensor the reference keeps for colour fusion (main_reconstruct.py:150). */
-int sn_cvc_forward(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
+SN_API int sn_cvc_forward(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
                    const float *mean6, const float *w, float *fused, float *unfused, float *cvc_out);
 /* viewPair_relativeImpt_fn (nets/SurfaceNet.py:334-338; used at utils/viewPairSelection.py:77):
  * features (n*n_vp, 258) float32 -> softmax weights (n, n_vp). */
-int sn_relative_weights(sn_ctx *ctx, int n, int n_vp, const float *features, float *weights);
+SN_API int sn_relative_weights(sn_ctx *ctx, int n, int n_vp, const float *features, float *weights);
 
 /* The weight computation of viewPairSelection.viewPairSelection (utils/viewPairSelection.py:63-77) for every 2-combination of
  * views (itertools.combinations order) in one call: embeddings (n_cubes,n_views,128), dissimilarity and theta (n_cubes,P)
  * float32 -> softmax weights (n_cubes,P). Bit-identical to building the (n_cubes*P,258) feature rows and calling
  * sn_relative_weights with n_vp = P. */
-int sn_viewpair_weights(sn_ctx *ctx, int n_cubes, int n_views, const float *embeddings, const float *dissimilarity,
+SN_API int sn_viewpair_weights(sn_ctx *ctx, int n_cubes, int n_views, const float *embeddings, const float *dissimilarity,
                         const float *theta, float *weights);
 
 /* utils.generate_voxelLevelWeighted_coloredCubes (utils/utils.py:8-42; call at main_reconstruct.py:150-152), float32 op for
  * op: cvc (n*n_vp,6,s,s,s) is the MEAN-SUBTRACTED tensor of sn_cvc_forward (the caller's `X += mean` is applied inside);
  * unfused (n,n_vp,s,s,s), w (n,n_vp) -> rgb (n,3,s,s,s) uint8. */
-int sn_color_fuse(sn_ctx *ctx, int n, int n_vp, const float *cvc, const float *mean6, const float *unfused, const float *w,
+SN_API int sn_color_fuse(sn_ctx *ctx, int n, int n_vp, const float *cvc, const float *mean6, const float *unfused, const float *w,
                   unsigned char *rgb);
-int sn_color_fuse_dev(sn_ctx *ctx, int n, int n_vp, const float *cvc_dev, const float *mean6, const float *unfused_dev,
+SN_API int sn_color_fuse_dev(sn_ctx *ctx, int n, int n_vp, const float *cvc_dev, const float *mean6, const float *unfused_dev,
                       const float *w_dev, unsigned char *rgb_dev);
 
 /* ---- hot path, device-resident (asynchronous on the context's stream) ------------------------- */
-void *sn_dev_alloc(sn_ctx *ctx, size_t bytes);
-int sn_dev_free(sn_ctx *ctx, void *p_dev);
-int sn_memcpy_h2d(sn_ctx *ctx, void *dst_dev, const void *src, size_t bytes);
-int sn_memcpy_d2h(sn_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
+SN_API void *sn_dev_alloc(sn_ctx *ctx, size_t bytes);
+SN_API int sn_dev_free(sn_ctx *ctx, void *p_dev);
+SN_API int sn_memcpy_h2d(sn_ctx *ctx, void *dst_dev, const void *src, size_t bytes);
+SN_API int sn_memcpy_d2h(sn_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
 /* Pipelined readback for loops that enqueue the next batch before they fetch the previous one (the reference's hot loop collects a
  * sparse list per cube and batch, main_reconstruct.py:126-160): sn_mark records point `slot` (0..7) on the context's stream;
  * sn_memcpy_d2h_after copies on a second stream as soon as that point has been reached and returns when the copy is done - work
  * enqueued on the context's stream AFTER the mark keeps running meanwhile (sn_memcpy_d2h would wait for all of it). */
-int sn_mark(sn_ctx *ctx, int slot);
-int sn_memcpy_d2h_after(sn_ctx *ctx, int slot, void *dst, const void *src_dev, size_t bytes);
+SN_API int sn_mark(sn_ctx *ctx, int slot);
+SN_API int sn_memcpy_d2h_after(sn_ctx *ctx, int slot, void *dst, const void *src_dev, size_t bytes);
 /* The HIP stream (hipStream_t) every asynchronous entry point of this context is ordered on, for interop: record / wait
  * events on it, or wrap it (e.g. torch.cuda.ExternalStream) to order collectives against the kernels without host syncs. */
-void *sn_stream(sn_ctx *ctx);
+SN_API void *sn_stream(sn_ctx *ctx);
 /* Same as sn_cvc_forward with every array already in HBM. n*n_vp <= max_samples. mean6 is host. */
-int sn_cvc_forward_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
+SN_API int sn_cvc_forward_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
                        const float *resol_dev, const float *mean6, const float *w_dev, float *fused_dev,
                        float *unfused_dev, float *cvc_out_dev);
-int sn_cvc_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
+SN_API int sn_cvc_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
                const float *resol_dev, const float *mean6, float *out_dev);
-int sn_forward_dev(sn_ctx *ctx, int n, int n_vp, const float *X_dev, const float *w_dev, float *fused_dev,
+SN_API int sn_forward_dev(sn_ctx *ctx, int n, int n_vp, const float *X_dev, const float *w_dev, float *fused_dev,
                    float *unfused_dev);
 
 /* ---- post-pass of the loop body (main_reconstruct.py:153-160) ------------------- */
@@ -150,10 +154,10 @@ int sn_forward_dev(sn_ctx *ctx, int n, int n_vp, const float *X_dev, const float
  * the call), view_pairs (n,n_vp,2) -> votes (n,s,s,s) uint8 (max 2*n_vp). use_thresh = 0 is prediction_thresh=None;
  * otherwise voxels with fp16(pred) > fp16(min_prob) take part. Needs sn_set_cameras only. SN_ERR_ARG if a projected
  * pixel / depth bin falls outside the int32 range (a cube on the camera plane; the reference has no such limit). */
-int sn_ray_pool(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
+SN_API int sn_ray_pool(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
                 const float *pred, int use_thresh, float min_prob, unsigned char *votes);
 /* Device-resident, asynchronous; the range error is reported by the next sn_synchronize. */
-int sn_ray_pool_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
+SN_API int sn_ray_pool_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
                     const float *resol_dev, const float *pred_dev, int use_thresh, float min_prob,
                     unsigned char *votes_dev);
 
@@ -171,12 +175,12 @@ typedef struct sn_sparse_cfg {
  *   ijk (total,3) uint8 | pred16 (total) float16 bits | rgb_out (total,3) uint8 | votes_out (total) uint8
  * Output arrays must hold n*Dc^3 entries (Dc = cube_Dcenter when cropping, else s); rgb_out / votes_out may be NULL.
  * votes_out is filled only when enable_rayPooling. The caller shifts xyz by resol*(s-Dc)/2 (sparseCubes.py:55). */
-int sn_dense2sparse(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
+SN_API int sn_dense2sparse(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs, const float *xyz, const float *resol,
                     const float *pred, const unsigned char *rgb, const sn_sparse_cfg *cfg, int64_t *offsets,
                     unsigned char *ijk, uint16_t *pred16, unsigned char *rgb_out, unsigned char *votes_out);
 /* Same with every array in HBM (offsets too); asynchronous. votes_ws_dev (n,s,s,s) uint8 scratch is required when
  * enable_rayPooling. */
-int sn_dense2sparse_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
+SN_API int sn_dense2sparse_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_dev, const float *xyz_dev,
                         const float *resol_dev, const float *pred_dev, const unsigned char *rgb_dev,
                         const sn_sparse_cfg *cfg, unsigned char *votes_ws_dev, int64_t *offsets_dev,
                         unsigned char *ijk_dev, uint16_t *pred16_dev, unsigned char *rgb_out_dev,
@@ -186,50 +190,50 @@ int sn_dense2sparse_dev(sn_ctx *ctx, int n, int n_vp, const int64_t *view_pairs_
 /* pickle.load + set_all_param_values([embedding layer, similarity layer]) of similarityNet_inference
  * (nets/similarityNet.py:229-244): 30 arrays in order — 13 x (conv W (Cout,Cin,3,3), b (Cout,)) for conv1_1 .. conv5_3
  * (cross-correlation, as Conv2DDNNLayer), embedding W (5888,128), b (128,), similarity W (1,1), b (1,). */
-int sn_simil_load_weights(sn_ctx *ctx, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params);
+SN_API int sn_simil_load_weights(sn_ctx *ctx, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params);
 /* image.cropImgPatches(img = view's image, pyramidRate = 1, cubeCenter_hw = (center_h, center_w)) (utils/image.py:92-183, as
  * called at utils/earlyRejection.py:50): n patches (n,64,64,3) uint8 RGB around the truncated centre projections,
  * coordinates clamped to the image. center_h / center_w: float64 (n,). Needs sn_set_images. */
-int sn_crop_patches(sn_ctx *ctx, int view, int n, const double *center_h, const double *center_w, unsigned char *patches);
+SN_API int sn_crop_patches(sn_ctx *ctx, int view, int n, const double *center_h, const double *center_w, unsigned char *patches);
 /* patch2embedding_fn (nets/similarityNet.py:219-221): preprocessed patches (n,3,64,64) float32 (BGR - mean) -> (n,128). */
-int sn_patch2embedding(sn_ctx *ctx, int n, const float *patches, float *embeddings);
+SN_API int sn_patch2embedding(sn_ctx *ctx, int n, const float *patches, float *embeddings);
 /* The inner loop of earlyRejection.patch2embedding (utils/earlyRejection.py:50-53) without leaving HBM: crop +
  * image.preprocess_patches (utils/image.py:9-36, mean_bgr[3]) + patch2embedding_fn for n cube centres of one view. */
-int sn_crop_embed(sn_ctx *ctx, int view, int n, const double *center_h, const double *center_w, const float *mean_bgr,
+SN_API int sn_crop_embed(sn_ctx *ctx, int view, int n, const double *center_h, const double *center_w, const float *mean_bgr,
                   float *embeddings);
 /* embeddingPair2simil_fn (nets/similarityNet.py:223-226): rows 2i, 2i+1 of emb_pairs (2*n_pairs,128) -> (n_pairs,1)
  * sigmoid(w * ||e1 - e2||_2 + b). */
-int sn_embeddingpair2simil(sn_ctx *ctx, int n_pairs, const float *emb_pairs, float *similarity);
+SN_API int sn_embeddingpair2simil(sn_ctx *ctx, int n_pairs, const float *emb_pairs, float *similarity);
 /* earlyRejection.embeddingPairs2simil (utils/earlyRejection.py:59-90) in one call: embeddings (n_cubes, n_views, 128) ->
  * similarity (n_cubes, n_views*(n_views-1)/2), pairs in itertools.combinations order; bit-identical to feeding the same pairs
  * through sn_embeddingpair2simil, without shipping every embedding once per pair across PCIe. */
-int sn_embeddings2simil(sn_ctx *ctx, int n_cubes, int n_views, const float *embeddings, float *similarity);
+SN_API int sn_embeddings2simil(sn_ctx *ctx, int n_cubes, int n_views, const float *embeddings, float *similarity);
 
 /* camera.perspectiveProj (utils/camera.py:123-184; calls at main_reconstruct.py:62-65 through perspectiveProj_cubesCorner):
  * V cameras x n points in one launch. P (V,3,4) float64 row-major, or NULL = the cameras of sn_set_cameras (V ignored);
  * xyz (n,3) float64 -> img_h, img_w (V,n) float64 (row v = camera v), depth (V,n) or NULL. Same arithmetic as the CVC
  * warp's projection (fp64 FMA chain over k, IEEE divide); round_int != 0 applies numpy's .round() (half-to-even) - the
  * caller casts to int64. */
-int sn_project_points(sn_ctx *ctx, int V, const double *P, int n, const double *xyz, int round_int, double *img_h,
+SN_API int sn_project_points(sn_ctx *ctx, int V, const double *P, int n, const double *xyz, int round_int, double *img_h,
                       double *img_w, double *depth);
 
 /* ---- multi-GPU (one process per GPU): the path's only exchange is an all-gather of the per-cube fused probabilities
  * (the reference is single-GPU, no counterpart). RCCL over xGMI; librccl is dlopen'ed on first use.
  * Rank 0 calls sn_comm_unique_id and ships the 128 bytes to the other ranks by any means; every rank then calls
  * sn_comm_init (collective). sn_allgather_f32_dev is asynchronous on the context's stream. */
-int sn_comm_unique_id(char *id128);
-int sn_comm_init(sn_ctx *ctx, int world, int rank, const char *id128);
-int sn_allgather_f32_dev(sn_ctx *ctx, const float *local_dev, size_t n_local, float *global_dev);
+SN_API int sn_comm_unique_id(char *id128);
+SN_API int sn_comm_init(sn_ctx *ctx, int world, int rank, const char *id128);
+SN_API int sn_allgather_f32_dev(sn_ctx *ctx, const float *local_dev, size_t n_local, float *global_dev);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream. While enabled every kernel launch is
  * bracketed by events; sn_profile_get drains them. idx enumerates kernel tags (layer names);
  * returns 1 past the last. flops / bytes are the ALGORITHMIC work of the recorded launches. */
-int sn_profile_enable(sn_ctx *ctx, int on);
-int sn_profile_count(sn_ctx *ctx);
-int sn_profile_get(sn_ctx *ctx, int idx, char *name, int name_cap, double *ms_total, int64_t *launches,
+SN_API int sn_profile_enable(sn_ctx *ctx, int on);
+SN_API int sn_profile_count(sn_ctx *ctx);
+SN_API int sn_profile_get(sn_ctx *ctx, int idx, char *name, int name_cap, double *ms_total, int64_t *launches,
                    double *flops, double *bytes);
-int sn_profile_reset(sn_ctx *ctx);
+SN_API int sn_profile_reset(sn_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,8 @@ def SurfaceNet_inference(N_viewPairs4inference, model_file, layerNameList_2_load
     drop-in accepts whichever of the two the caller's params selects; an int pins it (any other X then raises TypeError)."""
     values = param_values if param_values is not None else weights.load_lasagne_pickle(model_file)
     runtime.set_param_values(values)
+    if cube_D is not None:
+        runtime.prefer_cube_D(cube_D)
     N_vp = int(N_viewPairs4inference)
 
     def viewPair_relativeImpt_fn(similFeature, n_samples_perGroup=N_vp):

@@ -6,9 +6,10 @@
 
 Same signatures, result shapes / dtypes and ValueError contract as the reference; the arithmetic (fp64 FMA chain, IEEE
 divide, half-to-even rounding) is the CVC warp's and is checked bit for bit against vectors produced by the reference
-(`tests/test_gpu_dropin.py`). No CPU implementation lives here. The camera file readers and `cameraPs2Ts` stay with the
-caller (host I/O, out of scope); the camera centres the view-pair angles need are computed in
-`viewPairSelection.camera_centers`.
+(`tests/test_gpu_dropin.py`). No CPU projection lives here. `cameraPs2Ts` (utils/camera.py:103-120, called next to the readers at
+main_reconstruct.py:51) is kept with the reference's list-in / list-out contract on top of `viewPairSelection.camera_centers`. The
+camera FILE readers (`readCameraPOs_as_np`, utils/camera.py:8-81) are host I/O and stay with the caller: swap the
+functions, not the module - INTEGRATION.md §1.
 """
 import numpy as np
 
@@ -45,3 +46,13 @@ def perspectiveProj_cubesCorner(projection_M, cube_xyz_min, cube_D_mm, return_in
     corners = lo[:, None, :] + _CORNER_OFFSETS[None] * cube_D_mm          # numpy promotion as in the reference (int64 * scalar + array)
     h, w = _project(projection_M, corners.reshape((-1, 3)), return_int_hw, False)
     return h.reshape((-1, lo.shape[0], 8)), w.reshape((-1, lo.shape[0], 8))
+
+
+def cameraPs2Ts(cameraPOs):
+    """Camera centres of projection matrices (utils/camera.py:103-120): a list of (3,4) matrices gives a list of (3,) centres, an
+    array (V,3,4) gives an array (V,3). Host arithmetic, O(V), runs once per scene (`viewPairSelection.camera_centers`: C = -M^-1 p4,
+    equal to the reference's four 3x3 determinants up to rounding)."""
+    from .viewPairSelection import camera_centers
+    if type(cameraPOs) is list:
+        return [camera_centers(P)[0] for P in cameraPOs]
+    return camera_centers(cameraPOs)

@@ -109,11 +109,32 @@
 #ifndef SN_PP
 #define SN_PP 0           // 1: ping-pong K loop for the f16m8 3x3x3 kernels (merge_conv_a / merge_conv_b), see the slab loop
 #endif
+#ifndef SN_PPX
+#define SN_PPX 0          // 1: ping-pong K loop for the f16 / f16x3 3x3 kernels with at least two K-chunks per weight piece
+#endif
 #ifndef SN_PP_MERGE
 #define SN_PP_MERGE 0     // ping-pong: the two f16 chunks of a weight piece form ONE segment (2 * MF * NF MFMAs per burst, one barrier pair less per piece)
 #endif
 #ifndef SN_PP_WPRE
 #define SN_PP_WPRE 0      // ping-pong: the MX step's weight fragments are read in the load segments of the f16 chunks (1: all with the second, 2: split)
+#endif
+#ifndef SN_PP_WIN
+#define SN_PP_WIN 0       // ping-pong: the next segment's weight fragments are read from inside the MFMA burst (see compute_f16)
+#endif
+#ifndef SN_PP_WSPLIT
+#define SN_PP_WSPLIT 1    // SN_PP_WIN: weight DMA instalments issued with chunk 2p (the rest with chunk 2p+1, whose load segment is short)
+#endif
+#ifndef SN_PP_RESYNC
+#define SN_PP_RESYNC 1    // ping-pong: re-establish the group offset per tile so that both groups' epilogues overlap (see the tile loop)
+#endif
+#ifndef SN_PP_DESIG
+#define SN_PP_DESIG 0     // ping-pong: one designated wave per load slot issues that slot's weight DMAs (see stage_w_part)
+#endif
+#ifndef SN_PP_HSPREAD
+#define SN_PP_HSPREAD 0   // ping-pong: halo DMAs of the next slab spread over the slab's pieces (see halo_instalment)
+#endif
+#ifndef SN_PP_EARLYBAR
+#define SN_PP_EARLYBAR 0  // ping-pong: a slot's closing barrier in front of the burst's last MF MFMAs instead of behind them
 #endif
 #ifndef SN_PP_B128
 #define SN_PP_B128 0      // ping-pong MX segment: read the activation code slots whole (ds_read_b128) instead of their 12 code bytes (ds_read_b96)
@@ -168,6 +189,9 @@ enum { EPI_STORE = 0, EPI_FINAL = 1, EPI_POOL2D = 2, EPI_SIDEPOOL = 3 };   // PO
 // MFMA chain on the in-register outputs) and the 2x2x2 max-pool, run in the epilogue and store THEIR outputs (nets/SurfaceNet.py:37-38,46-47)
 
 __device__ __forceinline__ float sn_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Numeric status of one epilogue value: t = the pre-activation (folded BN of the accumulator), y = what is stored. ReLU maps a NaN or -inf
+// pre-activation to 0, so the test has to look at t: not finite (an accumulator that overflowed or met inf - inf upstream), or y beyond fp16.
+__device__ __forceinline__ bool sn_bad_value(float t, float y) { return !(fabsf(t) <= 3.0e38f) || !(y <= 65504.f); }
 
 // hi/lo split of an fp32 value into two fp16 (hi = rn(y), lo = rn(y - hi)); |y - hi - lo| <= 2^-22 |y|
 __device__ __forceinline__ void sn_split(float y, _Float16 &hi, _Float16 &lo)
@@ -389,7 +413,9 @@ conv3d_f16_mfma(ConvArgs a)
     // Preconditions (checked by launch_conv): only the first / last tile along an axis has out-of-volume halo voxels, and the
     // slab fits the offset field. The one-plane f16 mode of the 2-D nets (4-group slabs: up to 400 MB) keeps the generic path.
     constexpr bool BUFH = (K2D == 0) || (SPLIT != 0);
-    constexpr bool PP = SN_PP && SPLIT == 2 && K2D == 0 && NW_ == 8 && KS == 3 && SN_MX_FMT != 0;   // ping-pong K loop (slab loop)
+    constexpr bool PPM = SN_PP && SPLIT == 2 && K2D == 0 && NW_ == 8 && KS == 3 && SN_MX_FMT != 0;   // ping-pong K loop, f16m8 kernels (slab loop)
+    constexpr bool PPX = SN_PPX && SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && BUFH;          // ... f16 / f16x3 kernels
+    constexpr bool PP = PPM || PPX;
     constexpr unsigned FB_YLO = K2D ? (1u << 31) : HB_YLO, FB_YHI = K2D ? (1u << 30) : HB_YHI, FB_ZLO = K2D ? (1u << 29) : HB_ZLO,
                        FB_ZHI = K2D ? (1u << 28) : HB_ZHI, FB_NEVER = K2D ? 0x0FFFFFF0u : HB_ALWAYS, FB_OFFMASK = K2D ? 0x0FFFFFFFu : HB_OFFMASK;
     unsigned hword[HT];
@@ -432,7 +458,7 @@ conv3d_f16_mfma(ConvArgs a)
         toff = K2D ? ((y0 - C::R) * D + (z0 - C::R)) * 16 : (((x0 - C::RX) * D + (y0 - C::R)) * D + (z0 - C::R)) * 16;
     };
     // issues ALL of this wave's halo DMAs of (sample b [2-D: first image x0 of the tile], channel groups [c0, c0+c8n)) into halo buffer xb
-    auto stage_halo_buf = [&](int b, unsigned keep, int toff, int c0, int c8n, int xb) -> int {
+    auto stage_halo_buf = [&](int b, unsigned keep, int toff, int c0, int c8n, int xb, int kb = 0, int ke = 1 << 20) -> int {      // [kb, ke): this call's instalment of the wave's HT slots
         // opaque to the optimiser: otherwise it hoists (hword[k] & keep) + toff and the descriptors of BOTH candidate tiles out of the
         // K loop as loop invariants (8 VGPRs + 16 SGPRs live across it) and the accumulators spill
         if constexpr (PP) {      // (wave-uniform values that hipcc's divergence analysis loses inside the ping-pong piece loop)
@@ -460,7 +486,7 @@ conv3d_f16_mfma(ConvArgs a)
             constexpr int k = decltype(kc)::value;
             const int li = k * C::NW + wave;
             // (only the last slot of a wave can fall behind the last segment: HT = ceil(NSEG*NPL / NW))
-            if (k + 1 < HT || C::NSEG * NPL == HT * C::NW || li < C::NSEG * NPL) {
+            if ((k + 1 < HT || C::NSEG * NPL == HT * C::NW || li < C::NSEG * NPL) && k >= kb && k < ke) {
                 const char *base = (NPL > 1 && li >= C::NSEG) ? base0 + 2 * a.in_lo_off : base0;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, nrec, 0x00020000);
                 dma16_buf(rs, (hword[k] & keep) + (unsigned)toff, xbuf + xb * C::XBUF + li * 1024);
@@ -552,7 +578,7 @@ conv3d_f16_mfma(ConvArgs a)
         stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         wg_barrier();
-        if constexpr (PP) { if (wave >= C::NW / 2) wg_barrier(); }    // group 1 runs one barrier (= one segment slot) behind group 0
+        if constexpr (PP && !SN_PP_RESYNC) { if (wave >= C::NW / 2) wg_barrier(); }    // group 1 runs one barrier (= one segment slot) behind group 0
     }
 #if SN_STATIC_PRIO
     // static priority for the younger half of an 8-wave workgroup (MI355X_MICROARCH.md, two waves per SIMD): waves 4-7 lose
@@ -565,7 +591,6 @@ conv3d_f16_mfma(ConvArgs a)
     long long t_vm = 0, t_bar = 0, n_piece = 0, t_mx = 0, t_rel = 0, t_c0 = 0, t_dma = 0;
     const long long t_kernel0 = SN_TIMING ? __builtin_readcyclecounter() : 0;
     bool bad = false;   // a stored value left the fp16 range / is NaN (checked on the fp32 value in the epilogue)
-    constexpr float kF16Max = 65504.f;
 
     for (; tile < a.total_tiles; tile += tstride) {
         int b, x0, y0, z0;
@@ -591,6 +616,11 @@ conv3d_f16_mfma(ConvArgs a)
 
         int c0 = 0;
         size_t woff = 0;   // byte offset of the current slab in the weight stream
+        // SN_PP_RESYNC: the one-slot offset between the two wave groups is set up per TILE (group 1 waits one barrier here, group 0 one barrier
+        // behind its last segment), so that both groups run the epilogue at the same time. With a free-running offset the tile boundary costs
+        // two slots of (epilogue + load) each - a group's epilogue sits in its load slot while the partner's short MFMA burst ends and waits -
+        // which merge_conv_a's store epilogue cannot afford (+4 % against the non-ping-pong kernel before this, A/B r3e).
+        if constexpr (PP && SN_PP_RESYNC) { if (wave >= C::NW / 2) wg_barrier(); }
         for (int slab = 0; slab < a.nslab; ++slab) {
             const int c8n = a.slab_c8[slab];
             const int nchunk = chunks_of(c8n);
@@ -611,7 +641,98 @@ conv3d_f16_mfma(ConvArgs a)
             // fixed s_waitcnt vmcnt(HQ) or vmcnt(0), one scalar branch; the last instalment of a short slab takes whatever is left.
             int hdone = 0;
 
-            if constexpr (PP) {
+            if constexpr (PPX) {
+                // ---- PING-PONG K loop, f16 / f16x3 kernels (round 3) ---------------------------------------------------
+                // Same structure as the f16m8 loop below: a segment = one K-chunk; its NPLM * (MF + NF) operand fragments are read into registers in the
+                // wave's LOAD slot (with the tap offset of the next chunk and the wave's DMA duties), its (SPLIT ? 3 : 1) * MF * NF MFMAs run as one
+                // uninterrupted burst in its COMPUTE slot; wave group 1 runs one barrier behind group 0, so each SIMD's matrix pipe always
+                // belongs to exactly one wave. MFMA order per chunk = the software-pipelined loop's, so results are bit-identical to it.
+                // DMA duties: the next weight piece with the first chunk of a piece, the next slab's halo tile with the second chunk of a slab's
+                // first piece, the wait for the weights with the piece's last chunk (the halo, younger, may stay in flight: counted wait).
+                static_assert(C::PCH >= 2 && BUFH && SPLIT != 2, "ping-pong loop (f16 / f16x3): at least two chunks per weight piece");
+                const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
+                const unsigned xslab = xbuf_a + xb * C::XBUF;
+                constexpr int NPLM = C::NPLM;
+                int ko, ko_n = 0;
+                lds_read32<0>(ko, koff_a);
+                lgkm_wait<0>();
+                constexpr int WCNT = C::PCH * NF * NPL;                     // 1 KiB DMAs per (full) weight piece
+                constexpr int WPW = (WCNT + C::NW - 1) / C::NW;             // ... per wave
+                int p = 0;
+                do {
+                    const int ch0 = p * C::PCH;
+                    const unsigned wp = wbuf_a + wbi * C::WBUF;
+                    const int nseg = (nchunk - ch0) < C::PCH ? (nchunk - ch0) : C::PCH;      // chunks of this piece (>= 1)
+                    // the piece after this one: next piece of the slab (possibly short), else the first piece of the next slab / tile
+                    const bool w_next = (p + 1 < npiece) || have_next;
+                    const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
+                    int w_nch = C::PCH;
+                    if (p + 1 < npiece) { const int rem = wchunk - (ch0 + C::PCH); if (rem < C::PCH) w_nch = rem; }
+                    else { const int nch = wchunks_of(nc8n); if (nch < C::PCH) w_nch = nch; }
+                    int hnow = 0;
+                    static_for<0, C::PCH>([&](auto ccc) {
+                        constexpr int cc = decltype(ccc)::value;
+                        if (cc < nseg) {
+                            half8 xf[NPLM][MF], wf[NPLM][NF];
+                            const unsigned kos = xslab + (unsigned)ko;
+                            static_for<0, MF>([&](auto mc) {
+                                constexpr int m = decltype(mc)::value;
+                                lds_read128<0>(xf[0][m], (unsigned)xbase[m] + kos);
+                                if constexpr (SPLIT == 1) {
+                                    if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(xf[1][m], (unsigned)xbase[m] + kos);
+                                    else lds_read128<0>(xf[1][m], (unsigned)xbase[m] + kos + C::XPLANE);
+                                }
+                            });
+                            static_for<0, NF>([&](auto nc) {
+                                constexpr int n = decltype(nc)::value;
+                                lds_read128<(cc * NF + n) * C::MFRAG>(wf[0][n], wp);
+                                if constexpr (SPLIT == 1) lds_read128<(cc * NF + n) * C::MFRAG + 1024>(wf[1][n], wp);
+                            });
+                            lds_read32<0>(ko_n, koff_a + (unsigned)(ch0 + cc + 1) * 16);
+                            if constexpr (cc == 0) {
+                                if (w_next) {
+                                    const char *src = wsrc0 + w_off;
+                                    char *dst = wbuf + (wbi ^ 1) * C::WBUF;
+                                    const int cnt = w_nch * NF * NPL;
+                                    for (int i = wave; i < cnt; i += C::NW) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
+                                }
+                                if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                            }
+                            // the next slab's halo tile: second chunk of the slab's first piece (first chunk if the piece has only one)
+                            if (p == 0 && have_next && !(SN_ABL & 1) && cc == (nseg >= 2 ? 1 : 0))
+                                hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                            if (cc == nseg - 1) {
+                                // the next weight piece has landed; halo DMAs issued in THIS load segment may still fly unless the slab ends here
+                                if (p + 1 < npiece && cc == 1 && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
+                                else if (p + 1 < npiece && cc == 1 && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
+                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            }
+                            lgkm_wait<0>();
+                            ko = ko_n;
+                            wg_barrier();
+                            __builtin_amdgcn_sched_barrier(0);
+                            static_for<0, NF>([&](auto nc) {
+                                constexpr int n = decltype(nc)::value;
+                                if constexpr (SPLIT == 1) {
+#pragma unroll
+                                    for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][n], xf[0][m], acc[m][n], 0, 0, 0);
+#pragma unroll
+                                    for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][n], xf[1][m], acc[m][n], 0, 0, 0);
+                                }
+                                // SN_PP_EARLYBAR: the slot's closing barrier sits in FRONT of the burst's last MF MFMAs (all operands are in registers): the
+                                // partner's burst starts while they drain, which hides the barrier's own latency (~60 clocks of an idle matrix pipe per slot)
+                                if constexpr (SN_PP_EARLYBAR && n == NF - 1) { __builtin_amdgcn_sched_barrier(0); wg_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][n], xf[0][m], acc[m][n], 0, 0, 0);
+                            });
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (!SN_PP_EARLYBAR) wg_barrier();
+                        }
+                    });
+                    wbi ^= 1;
+                } while (++p < npiece);
+            } else
+            if constexpr (PPM) {
                 // ---- PING-PONG K loop (round 3) ------------------------------------------------------------------
                 // The two waves of a SIMD (wave w of group 0 = waves 0..3 and wave w + 4 of group 1) never compete for the matrix pipe: a
                 // SEGMENT (one K-chunk of f16 MFMAs, or one MX step) is LOADED - every operand fragment of the segment read from LDS into
@@ -634,16 +755,30 @@ conv3d_f16_mfma(ConvArgs a)
                 lgkm_wait<0>();
                 constexpr int WCNT = C::PCH * NF * NPL;                     // 1 KiB DMAs per weight piece
                 constexpr int WPW = (WCNT + C::NW - 1) / C::NW;             // ... per wave
+                int desig = slab;                        // rotates the DMA duty over the waves of a group
+                // SN_PP_DESIG: the LDS-DMAs of a load slot are issued by ONE wave of the loading group (rotating), the piece's WCNT items dealt to
+                // the four slots {group 0, group 1} x {chunk 2p, chunk 2p+1}. Issued by all four loading waves at once they queue on the CU's one
+                // texture-addresser (1 KiB = 16 clocks at 64 B/clk): measured 140-190 clocks per instruction and wave (SN_TIMING 7/8), i.e. every
+                // wave pays for everybody's; one wave pays 16 clocks per item and the other three nothing.
                 auto stage_w_part = [&](size_t off, int wb, int k0, int k1) {
                     const char *src = wsrc0 + off;
                     char *dst = wbuf + wb * C::WBUF;
+                    if constexpr (SN_PP_DESIG) {
+                        // k0 == 0: the first f16 chunk's slot (quarters 0, 1 = group 0, 1), else the second's (quarters 2, 3); k1 == WPW with k0 == 0
+                        // (piece without a second chunk): halves instead of quarters
+                        const int grp = wave >> 2, nq = (k0 == 0 && k1 == WPW) ? 2 : 4, q = (k0 == 0 ? 0 : 2) + grp;
+                        const int j0 = (WCNT * (nq == 2 ? grp : q)) / nq, j1 = (WCNT * ((nq == 2 ? grp : q) + 1)) / nq;
+                        if ((wave & 3) == (desig & 3))
+                            for (int j = j0; j < j1; ++j) dma16(src + (size_t)j * 1024 + lane * 16, dst + j * 1024);
+                    } else
                     for (int k = k0; k < k1; ++k) {
                         const int i = k * C::NW + wave;
                         if (i < WCNT) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
                     }
                 };
                 int p = 0;
-                do {                                     // (do-while: a possible zero-trip path made hipcc spill 88 accumulator registers around the loop)
+                do {
+                    ++desig;                                     // (do-while: a possible zero-trip path made hipcc spill 88 accumulator registers around the loop)
                     const int ch0 = p * C::PCH;
                     const unsigned wp = wbuf_a + wbi * C::WBUF;
                     // the piece after this one: next piece of the slab, else the first piece of the next slab / tile
@@ -651,12 +786,27 @@ conv3d_f16_mfma(ConvArgs a)
                     const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
                     const bool has_B = ch0 + 1 < nchunk;             // (the last piece of a slab with an odd chunk count has no second f16 chunk)
                     int hnow = 0;
+                    // SN_PP_HSPREAD: the next slab's halo DMAs are issued one slot of the wave's HT per piece (the slab's last piece takes what is left),
+                    // with the piece's second f16 chunk, instead of all HT in the first piece's MX load segment (4 x ~190 clocks in ONE slot)
+                    auto halo_instalment = [&]() {
+                        if constexpr (SN_PP_HSPREAD) {
+                            if (have_next && !(SN_ABL & 1))
+                                stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1,
+                                               p, p + 1 == npiece ? (1 << 20) : p + 1);
+                        }
+                    };
                     // SN_TIMING (diagnostic builds): shader-clock stamps 0 segment start | 1 operands landed | 2 barrier released | 3 MFMAs issued | 4 barrier released;
                     // odd values accumulate {load 0-1, wait 1-2}, even {compute 2-3, wait 3-4}; 1/2 all segments, 3/4 MX segments only, 5/6 f16 segments only
-                    long long ppt[5] = {0, 0, 0, 0, 0};
+                    long long ppt[5] = {0, 0, 0, 0, 0}, ppta = 0;
+#define PP_TA() do { if constexpr (SN_TIMING == 7 || SN_TIMING == 8) { ppta = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
 #define PP_T(i) do { if constexpr (SN_TIMING) { ppt[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
                     auto pp_account = [&](bool mx) {
                         if constexpr (SN_TIMING) {
+                            if constexpr (SN_TIMING == 9) {
+                            } else
+                            if constexpr (SN_TIMING >= 7) {            // 7: f16 segments, 8: MX segments: {DMA issue 0-a, LDS reads a-1} (the DMAs are issued FIRST in these builds)
+                                if ((SN_TIMING == 8) == mx) { t_vm += ppta - ppt[0]; t_bar += ppt[1] - ppta; ++n_piece; }
+                            } else
                             if ((SN_TIMING <= 2) || ((SN_TIMING <= 4) == mx)) {
                                 if (SN_TIMING & 1) { t_vm += ppt[1] - ppt[0]; t_bar += ppt[2] - ppt[1]; }
                                 else { t_vm += ppt[3] - ppt[2]; t_bar += ppt[4] - ppt[3]; }
@@ -684,12 +834,32 @@ conv3d_f16_mfma(ConvArgs a)
                             lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
                         });
                     };
-                    auto compute_f16 = [&](auto ccc) {
-                        constexpr int cc = decltype(ccc)::value;
-#pragma unroll
-                        for (int n = 0; n < NF; ++n)
+                    // SN_PP_WIN: the NEXT segment's weight fragments are requested from inside this burst, one fragment behind every group of MF MFMAs
+                    // (pre: 0 none | 1 the f16 fragments of chunk 2p+1 | 2 the MX step's): an LDS read costs a loading wave ~25 clocks (four waves
+                    // queueing on the LDS while the partners' MFMAs own the register-file ports) but a computing wave only its issue slot, of which
+                    // three in four are idle during the burst. The reads land during the wave's next load segment, whose lgkmcnt(0) covers them.
+                    auto compute_f16 = [&](auto ccc, auto prec, bool close = true) {
+                        constexpr int cc = decltype(ccc)::value, pre = decltype(prec)::value;
+                        static_for<0, NF>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            // SN_PP_EARLYBAR: the slot's closing barrier in front of the burst's last MF MFMAs (see the f16 / f16x3 loop)
+                            if constexpr (SN_PP_EARLYBAR && n == NF - 1) { if (close) { __builtin_amdgcn_sched_barrier(0); PP_T(3); wg_barrier(); __builtin_amdgcn_sched_barrier(0); } }
 #pragma unroll
                             for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);
+                            if constexpr (pre == 1) { lds_read128<(NF + n) * 1024>(wf[1][n], wp); __builtin_amdgcn_sched_barrier(0); }
+                            if constexpr (pre == 2) {
+                                if constexpr (n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
+                                lds_read128i<mxo + n * 2048>(wa4[n], wp);
+                                lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                    };
+                    using I2 = std::integral_constant<int, 2>;
+                    auto load_x = [&](auto ccc, int ko) {             // SN_PP_WIN: the activation fragments only
+                        constexpr int cc = decltype(ccc)::value;
+                        const unsigned kos = xslab + (unsigned)ko;
+                        static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<0>(xf[cc][m], (unsigned)xbase[m] + kos); });
                     };
                     using I0 = std::integral_constant<int, 0>;
                     using I1 = std::integral_constant<int, 1>;
@@ -699,6 +869,8 @@ conv3d_f16_mfma(ConvArgs a)
                     using INFA = std::integral_constant<int, NFA>;
                     using INFB = std::integral_constant<int, NFB>;
                     using INF = std::integral_constant<int, NF>;
+                    constexpr int WSPLIT = SN_PP_WIN ? SN_PP_WSPLIT : (WPW + 1) / 2;    // weight DMA instalments [0, WSPLIT) with chunk 2p, [WSPLIT, WPW) with chunk 2p+1
+                    static_assert(!(SN_PP_WIN && (SN_PP_WPRE || SN_PP_MERGE)), "SN_PP_WIN excludes SN_PP_WPRE / SN_PP_MERGE");
                     if constexpr (SN_PP_MERGE) {
                         // ---- segment F: both f16 chunks of the piece, 2 * MF * NF MFMAs in one burst; DMA: the next weight piece; tap table of the next slab
                         PP_T(0);
@@ -712,55 +884,69 @@ conv3d_f16_mfma(ConvArgs a)
                         wg_barrier();
                         PP_T(2);
                         __builtin_amdgcn_sched_barrier(0);
-                        compute_f16(I0{});
-                        if (has_B) compute_f16(I1{});
+                        compute_f16(I0{}, I0{}, !has_B);
+                        if (has_B) compute_f16(I1{}, I0{});
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_T(3);
-                        wg_barrier();
+                        if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
                         PP_T(4);
                         pp_account(false);
                     } else {
                         // ---- segment A: f16 chunk 2p; DMA: first half of the next weight piece; group 0 also writes the next slab's tap table
                         PP_T(0);
+                        if constexpr (SN_TIMING == 7 || SN_TIMING == 8) {
+                            if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WSPLIT);
+                            if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                            PP_TA();
+                        }
                         load_f16(I0{}, koA);
                         load_mxw(I0{}, INFA{});
-                        if (w_next) stage_w_part(w_off, wbi ^ 1, 0, (WPW + 1) / 2);
-                        if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                        if constexpr (!(SN_TIMING == 7 || SN_TIMING == 8)) {
+                            if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WSPLIT);
+                            if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                        }
                         lgkm_wait<0>();
                         PP_T(1);
                         wg_barrier();
                         PP_T(2);
                         __builtin_amdgcn_sched_barrier(0);
-                        compute_f16(I0{});
+                        // (chunk 2p+1's fragments are requested even when the piece has no such chunk - in-bounds reads of the zero padding, never
+                        // used: a burst per case doubled the kernel's register pressure)
+                        if constexpr (SN_PP_WIN) compute_f16(I0{}, I1{}); else compute_f16(I0{}, I0{});
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_T(3);
-                        wg_barrier();
+                        if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
                         PP_T(4);
                         pp_account(false);
                         // ---- segment B: f16 chunk 2p+1; DMA: second half
                         if (has_B) {
                             PP_T(0);
-                            load_f16(I1{}, koB);
+                            if constexpr (SN_TIMING == 7 || SN_TIMING == 8) { if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW); PP_TA(); }
+                            if constexpr (SN_PP_WIN) load_x(I1{}, koB); else load_f16(I1{}, koB);
                             load_mxw(INFA{}, INFB{});
-                            if (w_next) stage_w_part(w_off, wbi ^ 1, (WPW + 1) / 2, WPW);
+                            if constexpr (!(SN_TIMING == 7 || SN_TIMING == 8)) { if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW); }
+                            halo_instalment();
                             lgkm_wait<0>();
                             PP_T(1);
                             wg_barrier();
                             PP_T(2);
                             __builtin_amdgcn_sched_barrier(0);
-                            compute_f16(I1{});
+                            if constexpr (SN_PP_WIN) compute_f16(I1{}, I2{}); else compute_f16(I1{}, I0{});
                             __builtin_amdgcn_sched_barrier(0);
-                            PP_T(3);
-                            wg_barrier();
+                            if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
                             PP_T(4);
                             pp_account(false);
                         } else {
-                            if (w_next) stage_w_part(w_off, wbi ^ 1, (WPW + 1) / 2, WPW);
+                            if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW);
+                            halo_instalment();
                         }
                     }
                     // ---- segment M: the MX step of the piece's 64 k; DMA: the next slab's halo tile (first piece of a slab); waits for the weights
                     {
                         PP_T(0);
+                        if constexpr (SN_TIMING == 7 || SN_TIMING == 8) {
+                            if (p == 0 && have_next)
+                                hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                            PP_TA();
+                        }
                         v3i x6[MF][2];
                         v4i x8h[MF][2];                                       // SN_PP_B128: whole slots (4 LDS cycles per read instead of 8; the pad dword is dropped below)
                         int koAn = 0, koBn = 0;
@@ -776,6 +962,9 @@ conv3d_f16_mfma(ConvArgs a)
                                 lds_read96i<0>(x6[m][1], (unsigned)xbase[m] + ks1);
                             }
                         });
+                        if constexpr (SN_PP_WIN && !SN_PP_MERGE) {
+                            if (!has_B) load_mxw(I0{}, INF{});              // (else: requested from inside chunk 2p+1's burst)
+                        } else
                         if (!(SN_PP_WPRE && (SN_PP_MERGE || has_B))) {
                             if constexpr (SN_PP_WPRE == 0 || SN_PP_MERGE) load_mxw(I0{}, INF{});
                             else load_mxw(INFA{}, INF{});                  // (no chunk 2p+1 in this piece: its share of the fragments is read here)
@@ -786,15 +975,22 @@ conv3d_f16_mfma(ConvArgs a)
                             lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
                         }
 #ifndef SN_PP_NOHALO
-                        if (p == 0 && have_next && !(SN_ABL & 1))
+                        if (!SN_PP_HSPREAD && !(SN_TIMING == 7 || SN_TIMING == 8) && p == 0 && have_next && !(SN_ABL & 1))
 #else
                         if (0)
 #endif
                             hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                        long long pptv = 0;
+                        if constexpr (SN_TIMING == 9) { lgkm_wait<0>(); pptv = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                         // the next weight piece (issued two load slots ago) has landed; this slab's halo DMAs, just issued, may still fly
                         if (p + 1 < npiece && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
                         else if (p + 1 < npiece && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if constexpr (SN_TIMING == 9) {      // 9: MX segments {the vmcnt wait alone, everything in front of it}
+                            const long long tq = __builtin_readcyclecounter();
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            t_vm += tq - pptv; t_bar += pptv - ppt[0]; ++n_piece;
+                        }
                         lgkm_wait<0>();
                         v8i x8[MF], wa[NF];
 #pragma unroll
@@ -826,17 +1022,18 @@ conv3d_f16_mfma(ConvArgs a)
                         static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
                             const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
+                            if constexpr (SN_PP_EARLYBAR && n == NF - 1) { __builtin_amdgcn_sched_barrier(0); PP_T(3); wg_barrier(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                             for (int m = 0; m < MF; ++m)
                                 acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
                         });
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_T(3);
-                        wg_barrier();
+                        if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
                         PP_T(4);
                         pp_account(true);
                     }
 #undef PP_T
+#undef PP_TA
                     wbi ^= 1;
                 } while (++p < npiece);
             } else {
@@ -1196,6 +1393,7 @@ conv3d_f16_mfma(ConvArgs a)
             woff += (size_t)wchunk * NF * C::FRAG;
         }
 
+        if constexpr (PP && SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }     // pairs with group 1's last compute segment of the tile
         // ---- epilogue: folded BN affine + activation --------------------------------------------------------
         if constexpr (EPI == EPI_STORE && (SN_ABL & 512)) {
             // ablation 512: keep the accumulators live, store nothing
@@ -1230,11 +1428,12 @@ conv3d_f16_mfma(ConvArgs a)
                     float lo32[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float y = fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f);
-                        if constexpr (R2) y = fmaxf(y, fmaxf(acc[m + 1 < MF ? m + 1 : m][n][r] * sc[r] + sh[r], 0.f));
+                        const float t0 = acc[m][n][r] * sc[r] + sh[r], t1 = R2 ? acc[m + 1 < MF ? m + 1 : m][n][r] * sc[r] + sh[r] : t0;
+                        float y = fmaxf(t0, 0.f);
+                        if constexpr (R2) y = fmaxf(y, fmaxf(t1, 0.f));
+                        bad |= sn_bad_value(t0, y) || sn_bad_value(t1, y);
                         y = fmaxf(y, __shfl_xor(y, 1));
                         if constexpr (!R2) y = fmaxf(y, __shfl_xor(y, YX));
-                        bad |= !(y <= kF16Max);
                         if constexpr (OSPLIT == 1) {
                             _Float16 hh, ll;
                             sn_split(y, hh, ll);
@@ -1277,8 +1476,8 @@ conv3d_f16_mfma(ConvArgs a)
                 for (int m = 0; m < MF; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float t = fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f);
-                        bad |= !(t <= kF16Max);
+                        const float pre = acc[m][n][r] * sc[r] + sh[r], t = fmaxf(pre, 0.f);
+                        bad |= sn_bad_value(pre, t);
                         y[m][n][r] = t;
                     }
             }
@@ -1328,9 +1527,9 @@ conv3d_f16_mfma(ConvArgs a)
                         float lo32[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float t = sacc[mp + e][r] * ssc[r] + ssh[r];
-                            t = a.side_act == 0 ? fmaxf(t, 0.f) : sn_sigmoid(t);
-                            bad |= !(t <= kF16Max);
+                            const float pre = sacc[mp + e][r] * ssc[r] + ssh[r];
+                            float t = a.side_act == 0 ? fmaxf(pre, 0.f) : sn_sigmoid(pre);
+                            bad |= sn_bad_value(pre, t);
                             if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
                                 sn_split(t, hh, ll);
@@ -1465,9 +1664,9 @@ conv3d_f16_mfma(ConvArgs a)
                         float lo32[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float y = acc[mp + e][n][r] * sc[r] + sh[r];
-                            y = a.act == 0 ? fmaxf(y, 0.f) : sn_sigmoid(y);
-                            bad |= !(y <= kF16Max);          // (false for NaN: flagged too; y >= 0 after either activation)
+                            const float pre = acc[mp + e][n][r] * sc[r] + sh[r];
+                            float y = a.act == 0 ? fmaxf(pre, 0.f) : sn_sigmoid(pre);
+                            bad |= sn_bad_value(pre, y);     // (the pre-activation: ReLU would turn a NaN / -inf accumulator into a clean 0)
                             if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
                                 sn_split(y, hh, ll);
@@ -1543,7 +1742,7 @@ conv3d_f16_mfma(ConvArgs a)
             }
         }
     }
-    if constexpr (PP) { if (wave < C::NW / 2) wg_barrier(); }       // pairs with group 1's last compute segment
+    if constexpr (PP && !SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }       // pairs with group 1's last compute segment
     if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, a.status_bit);
     if constexpr (SN_TIMING) {
         if (a.status && lane == 0) {        // [2..9]: per layer-bit slot of 4 x u64: kernel cycles, vmcnt-wait cycles, barrier-wait cycles, pieces (summed over waves)

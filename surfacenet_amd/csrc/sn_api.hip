@@ -285,8 +285,8 @@ static TileChoice tile_for(const LayerSpec &sp, int split)
     if (sp.kind == K_CONV1 || sp.kind == K_DIL1) return {1, 1, 5};
     if (sp.kind == K_DIL3) return {5, 4, 1};        // conv4: dilation-2 halo is big -> 8-channel slabs; 4 x 80 output channels
     if (sp.cout == 32) return {2, 1, 1};
-    if (sp.cout == 80) return {5, 1, split == 2 ? 1 : 2};
-    if (sp.cout == 160) return {5, 2, split == 2 ? 1 : 2};
+    if (sp.cout == 80) return {5, 1, (split == 2 || SN_PPX) ? 1 : 2};
+    if (sp.cout == 160) return {5, 2, (split == 2 || SN_PPX) ? 1 : 2};
     // cout 100 (merge_conv_a/b). f16 mode has LDS room for two 8-channel groups per slab in merge_conv_a (-18 % there)
     return {7, 1, (split == 0 && sp.cin == 64) ? 2 : 1};
 }
@@ -329,8 +329,12 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
 #define RUN(x) do { if ((rc = (x)) != SN_OK) return rc; } while (0)
 #define CONV1 3, 1, 4, 2, EPI_STORE, SP, 1, (SP == 2 ? 2 : 7), 8, 0
 #define SIDE  1, 1, 4, 1, EPI_STORE, SP, 5, 2, 4, 0
-#define CONV2 3, 1, 4, 5, EPI_STORE, SP, (SP == 2 ? 1 : 2), (SP == 2 ? 2 : 1), 8, 0
-#define CONV3 3, 1, 4, 5, EPI_STORE, SP, (SP == 2 ? 1 : 2), (SP == 2 ? 2 : 1), 8, 0
+// conv2_x / conv3_x: 16-channel slabs with one-chunk weight pieces; the ping-pong loop (SN_PPX) needs >= 2 chunks per piece, which fits the
+// LDS only with 8-channel slabs (4-chunk pieces: a 7-chunk slab = pieces of 4 + 3)
+#define C23_CS8 (SP == 2 ? 1 : (SN_PPX ? 1 : 2))
+#define C23_PCH (SP == 2 ? 2 : (SN_PPX ? 4 : 1))
+#define CONV2 3, 1, 4, 5, EPI_STORE, SP, C23_CS8, C23_PCH, 8, 0
+#define CONV3 3, 1, 4, 5, EPI_STORE, SP, C23_CS8, C23_PCH, 8, 0
 #define CONV4 3, 2, 4, 5, EPI_STORE, SP, 1, 2, 8, 0
 // f16 mode (one activation plane): 4-chunk weight pieces halve the barriers; merge_conv_a also takes 16-channel slabs
 #define MERGA 3, 1, 4, 7, EPI_STORE, SP, (SP == 0 ? 2 : 1), (SP == 0 ? 4 : 2), 8, 0
@@ -359,7 +363,7 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     if (!unfused) {
         // conv2_3 likewise: side_op2 (-> the 16-channel half-resolution side map) and pool2 in its epilogue (nets/SurfaceNet.py:44-47)
         const SideFuse sf2{&L["side_op2"], s2, 16, 0, p2, 80};
-        RUN((launch_conv<3, 1, 4, 5, EPI_SIDEPOOL, SP, (SP == 2 ? 1 : 2), (SP == 2 ? 2 : 1), 8, 0>(c, L["conv2_3"], b2, 80, none, 0, 0, 80, nullptr, S, D2, 0, &sf2)));
+        RUN((launch_conv<3, 1, 4, 5, EPI_SIDEPOOL, SP, C23_CS8, C23_PCH, 8, 0>(c, L["conv2_3"], b2, 80, none, 0, 0, 80, nullptr, S, D2, 0, &sf2)));
     } else {
         RUN((launch_conv<CONV2>(c, L["conv2_3"], b2, 80, a2, 80, 0, 80, nullptr, S, D2)));
         RUN((launch_conv<SIDE>(c, L["side_op2"], a2, 80, s2, 16, 0, 16, nullptr, S, D2)));
@@ -1144,9 +1148,10 @@ int sn_memcpy_d2h_after(sn_ctx *c, int slot, void *dst, const void *src, size_t 
     return SN_OK;
 }
 
+#ifdef SN_DEBUG_HOOKS     // test-only twin library (Makefile target dbg): not in the product .so, not in the ABI header
 // Test hook (not part of the ABI header): raw copy of an internal activation buffer ("cat": concat buffer, "ma": merge_conv_a output;
 // both planes, layout of DESIGN.md section 3) for comparing the device's stored codes with oracle/net_emulation.py.
-int sn_debug_tensor(sn_ctx *c, const char *name, void *host, size_t bytes)
+SN_API int sn_debug_tensor(sn_ctx *c, const char *name, void *host, size_t bytes)
 {
     if (!c || !name || !host) return fail(SN_ERR_ARG, "null argument");
     const _Float16 *p = !strcmp(name, "cat") ? c->cat : (!strcmp(name, "ma") ? c->ma : nullptr);
@@ -1159,11 +1164,11 @@ int sn_debug_tensor(sn_ctx *c, const char *name, void *host, size_t bytes)
 
 // Test hook (not part of the ABI header): the host-side 6-bit encoder the weight packer uses, so that a CPU test can pin it against the
 // format's decode table (tests/test_abi.py) - the device side of the format is pinned by tools/probe/fp6_probe.hip.
-int sn_debug_mx6_encode(float v, int fmt) { return (fmt == 2 || fmt == 3) ? (int)mx6_encode(v, fmt) : -1; }
+SN_API int sn_debug_mx6_encode(float v, int fmt) { return (fmt == 2 || fmt == 3) ? (int)mx6_encode(v, fmt) : -1; }
 
 // Diagnostic builds only (-DSN_TIMING=1, conv3d_mfma.h): per-layer shader-clock totals {kernel, vmcnt wait, barrier wait, pieces} summed over
 // waves, in layer-bit order (names: sn_synchronize's message order). Not part of the ABI header; reads and clears the slots.
-int sn_debug_timing(sn_ctx *c, unsigned long long *out, int n_layers, char *names, int names_cap)
+SN_API int sn_debug_timing(sn_ctx *c, unsigned long long *out, int n_layers, char *names, int names_cap)
 {
     if (!c || !out || !c->d_num) return fail(SN_ERR_ARG, "null argument");
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1176,13 +1181,15 @@ int sn_debug_timing(sn_ctx *c, unsigned long long *out, int n_layers, char *name
     return SN_OK;
 }
 // workgroup 0 of the last EPI_FINAL launch: [2048 pieces][8 waves]{arrival at the barrier, release} shader clocks
-int sn_debug_trace(sn_ctx *c, long long *out)
+SN_API int sn_debug_trace(sn_ctx *c, long long *out)
 {
     if (!c || !out || !c->d_num) return fail(SN_ERR_ARG, "null argument");
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->d_num + 2 + 32 * 8, sizeof(long long) * 2048 * 8 * 2, hipMemcpyDeviceToHost));
     return SN_OK;
 }
+
+#endif  // SN_DEBUG_HOOKS
 
 // ---- profiling ----------------------------------------------------------------------------------------
 int sn_profile_enable(sn_ctx *c, int on)

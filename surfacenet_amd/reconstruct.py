@@ -260,9 +260,10 @@ def gather_sparse_sharded(local, lo, group=None, device=None):
     allb = torch.empty((world * cap,), dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(allb, buf, group=group)
     allb = allb.cpu().numpy()
+    sizes_h = sizes.cpu().numpy()           # one device-to-host copy, not one per rank
     out = ([], [], [], [], [], [])
     for r in range(world):
-        b = allb[r * cap: r * cap + int(sizes[r].item())]
+        b = allb[r * cap: r * cap + int(sizes_h[r])]
         nh, nx = (int(v) for v in b[:16].view(np.int64))
         h = b[16:16 + 8 * nh].view(np.int64)
         o = 16 + 8 * nh
@@ -284,19 +285,8 @@ def gather_sparse_sharded(local, lo, group=None, device=None):
     return out[0], out[1], out[2], out[3], out[4], np.concatenate(out[5], axis=0)
 
 
-def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, patch2embedding_fn,
-                      embeddingPair2simil_fn, viewPair_relativeImpt_fn, cube_Dcenter, patches_mean_bgr, batchSize_similNet_patch2embedding=100,
-                      batchSize_similNet_embeddingPair2simil=100000, batchSize_viewPair_w=100000, batchSize_nViewPair_SurfaceNet=None,
-                      weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64, ctx=None, timings=None):
-    """The body of main_reconstruct.reconstruction() between file input and PLY output (main_reconstruct.py:67-173):
-    corner / centre projections -> early rejection (similarityNet) -> view-pair selection (relative-weight MLP) ->
-    per batch: CVC, SurfaceNet, fusion, voxel colours, ray pooling, dense2sparse -> thinning masks.
-    The three *_fn arguments are the callables of similarityNet.similarityNet_inference / SurfaceNet.SurfaceNet_inference
-    (their weights are bound in `runtime`). Returns a dict with the reference's variable names. Not included (SURVEY §2.1,
-    out of scope): image / camera readers, cube tiling, cross-cube denoising, PLY / npz writers.
-    `timings` (optional dict) receives the wall seconds of every stage."""
+def _lap_fn(timings):
     import time
-    from . import camera, earlyRejection, runtime, sparseCubes, viewPairSelection
     clock = [time.perf_counter()]
 
     def lap(name):
@@ -304,19 +294,33 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
             now = time.perf_counter()
             timings[name] = timings.get(name, 0.0) + (now - clock[0])
             clock[0] = now
+    return lap
 
+
+def scene_select(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, patch2embedding_fn, embeddingPair2simil_fn,
+                 viewPair_relativeImpt_fn, patches_mean_bgr, batchSize_similNet_patch2embedding=100, batchSize_similNet_embeddingPair2simil=100000,
+                 batchSize_viewPair_w=100000, weighted_fusion=True, D_embedding=128, patchSize=64, ctx=None, timings=None):
+    """main_reconstruct.py:67-116 for the cubes given: corner / centre projections -> early rejection (similarityNet) -> view-pair selection
+    (relative-weight MLP). Every step is per cube, so any subset of the scene's cubes gives that subset's rows. Returns a dict with the
+    reference's variable names: patches_embedding (N,V,128), inScope_cubes_vs_views (N,V), dissimilarity (N,P), validCubes (N,) and - when any
+    cube is valid - viewPairs4Reconstr (Nv,N_vp,2), w_viewPairs4Reconstr (Nv,N_vp)."""
+    from . import camera, earlyRejection, runtime, viewPairSelection
+    lap = _lap_fn(timings)
     cameraPOs_np = np.asarray(cameraPOs_np, dtype=np.float64)
-    N_vp = int(N_viewPairs4inference)
+    N_vp, N_views, N_cubes = int(N_viewPairs4inference), cameraPOs_np.shape[0], len(cubes_param_np)
+    viewPairs = viewPairSelection.k_combination_np(range(N_views), k=2)
+    if N_cubes == 0:           # an empty shard (more ranks than cubes): the projections below cannot reshape zero points
+        return dict(patches_embedding=np.zeros((0, N_views, D_embedding), np.float32), inScope_cubes_vs_views=np.zeros((0, N_views), bool),
+                    dissimilarity=np.zeros((0, len(viewPairs)), np.float32), validCubes=np.zeros((0,), bool))
+    runtime.prefer_cube_D(cube_D if ctx is None else ctx.cube_D)    # the projections / early rejection below use the scene's own context
     # main_reconstruct.py:67-71
     img_h_cubesCorner, img_w_cubesCorner = camera.perspectiveProj_cubesCorner(projection_M=cameraPOs_np, cube_xyz_min=cubes_param_np['xyz'],
                                                                               cube_D_mm=cube_D_mm, return_int_hw=False, return_depth=False)
     img_h_cubesCenter, img_w_cubesCenter = camera.perspectiveProj(projection_M=cameraPOs_np, xyz_3D=cubes_param_np['xyz'] + cube_D_mm / 2.,
                                                                   return_int_hw=False, return_depth=False)
-    N_views, N_cubes = img_h_cubesCorner.shape[:2]
     cameraTs_np = viewPairSelection.camera_centers(cameraPOs_np)                                    # main_reconstruct.py:50
     lap("projections")
     # :84-97 early rejection
-    viewPairs = viewPairSelection.k_combination_np(range(N_views), k=2)
     patches_embedding, inScope_cubes_vs_views = earlyRejection.patch2embedding(
         images_list, img_h_cubesCorner, img_w_cubesCorner, patch2embedding_fn, patches_mean_bgr, N_cubes, N_views, D_embedding, patchSize=patchSize,
         batchSize=batchSize_similNet_patch2embedding, cubeCenter_hw=np.stack([img_h_cubesCenter, img_w_cubesCenter], axis=0))
@@ -326,9 +330,7 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
                                                         batchSize=batchSize_similNet_embeddingPair2simil)
     validCubes = earlyRejection.selectFromSimilarity(dissimilarityProb=dissimilarity, N_viewPairs4inference=N_vp)
     lap("pair_similarity")
-    out = dict(patches_embedding=patches_embedding, inScope_cubes_vs_views=inScope_cubes_vs_views, dissimilarity=dissimilarity, validCubes=validCubes,
-               prediction_list=[], rgb_list=[], vxl_ijk_list=[], rayPooling_votes_list=[], cube_ijk_np=None, param_np=None, viewPair_np=None,
-               vxl_mask_list=[])
+    out = dict(patches_embedding=patches_embedding, inScope_cubes_vs_views=inScope_cubes_vs_views, dissimilarity=dissimilarity, validCubes=validCubes)
     if not validCubes.any():
         return out
     # :103-116 view-pair selection
@@ -340,28 +342,94 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
         w_viewPairs4Reconstr[:] = 1.0 / N_vp
     out.update(viewPairs4Reconstr=viewPairs4Reconstr, w_viewPairs4Reconstr=w_viewPairs4Reconstr)
     lap("viewpair_selection")
-    # :126-166 the cube-batch loop, device-resident
+    return out
+
+
+_LOOP_EMPTY = dict(prediction_list=[], rgb_list=[], vxl_ijk_list=[], rayPooling_votes_list=[], cube_ijk_np=None, param_np=None, viewPair_np=None,
+                   vxl_mask_list=[])
+
+
+def scene_cube_loop(images_list, cameraPOs_np, valid_cubes_param_np, viewPairs4Reconstr, w_viewPairs4Reconstr, cube_D, N_viewPairs4inference,
+                    cube_Dcenter, batchSize_nViewPair_SurfaceNet=None, min_prob=0.46, tau=0.7, gamma=0.8, ctx=None, timings=None):
+    """main_reconstruct.py:126-173 for a run of VALID cubes (their rows of the cube table, their selected view pairs and weights): per batch
+    CVC, SurfaceNet, fusion, voxel colours, ray pooling, dense2sparse - device-resident (`SparseLoop.run_many`) - then the thinning masks.
+    Returns prediction_list, rgb_list, vxl_ijk_list, rayPooling_votes_list, vxl_mask_list, param_np, viewPair_np, cube_ijk_np (rows of the
+    non-empty cubes), as the reference accumulates them."""
+    from . import runtime, sparseCubes
+    lap = _lap_fn(timings)
+    out = {k: (list(v) if isinstance(v, list) else v) for k, v in _LOOP_EMPTY.items()}
+    if len(valid_cubes_param_np) == 0:
+        return out
+    N_vp = int(N_viewPairs4inference)
     ctx = ctx or runtime.context_for(cube_D)
-    runtime.bind_scene(ctx, cameraPOs_np, images_list)
+    runtime.bind_scene(ctx, np.asarray(cameraPOs_np, dtype=np.float64), images_list)
     bs = int(batchSize_nViewPair_SurfaceNet or max(1, ctx.max_samples // N_vp))
     bs = min(bs, max(1, ctx.max_samples // N_vp))
     loop = SparseLoop(ctx, N_vp, max_cubes=bs, min_prob=min_prob, rayPool_thresh=0, enable_centerCrop=True, cube_Dcenter=cube_Dcenter,
                       enable_rayPooling=True)
     try:
         # the batches of gen_non0Batch_npBool(validCubes, bs) are consecutive runs of valid cubes: run_many walks exactly those
-        nonempty, ijk_l, p_l, rgb_l, v_l, xyz_new = loop.run_many(viewPairs4Reconstr, cubes_param_np['xyz'][validCubes],
-                                                                  cubes_param_np['resol'][validCubes], w_viewPairs4Reconstr)
+        nonempty, ijk_l, p_l, rgb_l, v_l, xyz_new = loop.run_many(viewPairs4Reconstr, valid_cubes_param_np['xyz'], valid_cubes_param_np['resol'],
+                                                                  w_viewPairs4Reconstr)
     finally:
         loop.close()
     lap("cube_loop")
-    param_sub = np.copy(cubes_param_np[validCubes])
+    param_sub = np.copy(valid_cubes_param_np)
     param_sub['xyz'] = xyz_new
     out.update(prediction_list=p_l, rgb_list=rgb_l, vxl_ijk_list=ijk_l, rayPooling_votes_list=v_l, param_np=param_sub[nonempty],
-               viewPair_np=viewPairs4Reconstr.astype(np.uint16)[nonempty], cube_ijk_np=cubes_param_np['ijk'][validCubes][nonempty])
+               viewPair_np=np.asarray(viewPairs4Reconstr).astype(np.uint16)[nonempty], cube_ijk_np=valid_cubes_param_np['ijk'][nonempty])
     # :172-173 thinning
     out["vxl_mask_list"] = sparseCubes.filter_voxels(vxl_mask_list=[], prediction_list=out["prediction_list"], prob_thresh=tau,
                                                      rayPooling_votes_list=out["rayPooling_votes_list"], rayPool_thresh=gamma * N_vp * 2)
     lap("thinning")
+    return out
+
+
+_SELECT_KEYS = ("patch2embedding_fn", "embeddingPair2simil_fn", "viewPair_relativeImpt_fn", "patches_mean_bgr", "batchSize_similNet_patch2embedding",
+                "batchSize_similNet_embeddingPair2simil", "batchSize_viewPair_w", "weighted_fusion", "D_embedding", "patchSize")
+_LOOP_KEYS = ("cube_Dcenter", "batchSize_nViewPair_SurfaceNet", "min_prob", "tau", "gamma")
+
+
+def _scene_args(args, kwargs):
+    """reconstruct_scene's positional tail (patch2embedding_fn, embeddingPair2simil_fn, viewPair_relativeImpt_fn, cube_Dcenter, patches_mean_bgr)
+    and keywords -> (keywords of scene_select, keywords of scene_cube_loop)."""
+    names = ("patch2embedding_fn", "embeddingPair2simil_fn", "viewPair_relativeImpt_fn", "cube_Dcenter", "patches_mean_bgr")
+    if len(args) > len(names):
+        raise TypeError("too many positional arguments")
+    kw = dict(zip(names, args))
+    for k, v in kwargs.items():
+        if k in kw:
+            raise TypeError("%s given twice" % k)
+        kw[k] = v
+    unknown = set(kw) - set(_SELECT_KEYS) - set(_LOOP_KEYS) - {"ctx", "timings"}
+    if unknown:
+        raise TypeError("unexpected arguments %s" % sorted(unknown))
+    sel = {k: kw[k] for k in _SELECT_KEYS if k in kw}
+    loop = {k: kw[k] for k in _LOOP_KEYS if k in kw}
+    for d in (sel, loop):
+        d["ctx"], d["timings"] = kw.get("ctx"), kw.get("timings")
+    return sel, loop
+
+
+def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, *args, **kwargs):
+    """The body of main_reconstruct.reconstruction() between file input and PLY output (main_reconstruct.py:67-173):
+    corner / centre projections -> early rejection (similarityNet) -> view-pair selection (relative-weight MLP) ->
+    per batch: CVC, SurfaceNet, fusion, voxel colours, ray pooling, dense2sparse -> thinning masks  (= `scene_select` + `scene_cube_loop`).
+    Arguments after N_viewPairs4inference: patch2embedding_fn, embeddingPair2simil_fn, viewPair_relativeImpt_fn (the callables of
+    similarityNet.similarityNet_inference / SurfaceNet.SurfaceNet_inference; their weights are bound in `runtime`), cube_Dcenter,
+    patches_mean_bgr, then keywords: batchSize_similNet_patch2embedding=100, batchSize_similNet_embeddingPair2simil=100000,
+    batchSize_viewPair_w=100000, batchSize_nViewPair_SurfaceNet=None, weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8,
+    D_embedding=128, patchSize=64, ctx=None, timings=None (a dict that receives the wall seconds of every stage).
+    Returns a dict with the reference's variable names. Not included (out of scope): image / camera readers, cube tiling,
+    cross-cube denoising, PLY / npz writers."""
+    sel_kw, loop_kw = _scene_args(args, kwargs)
+    out = scene_select(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, **sel_kw)
+    valid = out["validCubes"]
+    if not valid.any():
+        out.update({k: (list(v) if isinstance(v, list) else v) for k, v in _LOOP_EMPTY.items()})
+        return out
+    out.update(scene_cube_loop(images_list, cameraPOs_np, cubes_param_np[valid], out["viewPairs4Reconstr"], out["w_viewPairs4Reconstr"], cube_D,
+                               N_viewPairs4inference, **loop_kw))
     return out
 
 
@@ -373,26 +441,57 @@ def _allgather_bytes(blob, group=None, device=None):
     world = dist.get_world_size(group)
     sizes = torch.zeros((world,), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(sizes, torch.tensor([blob.size], dtype=torch.int64, device=device), group=group)
-    cap = max(1, int(sizes.max().item()))
+    sizes = sizes.cpu().numpy()                      # one device-to-host copy
+    cap = max(1, int(sizes.max()))
     buf = torch.zeros((cap,), dtype=torch.uint8, device=device)
     buf[: blob.size] = torch.from_numpy(np.ascontiguousarray(blob)).to(buf.device)
     allb = torch.empty((world * cap,), dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(allb, buf, group=group)
     allb = allb.cpu().numpy()
-    return [allb[r * cap: r * cap + int(sizes[r].item())] for r in range(world)]
+    return [allb[r * cap: r * cap + int(sizes[r])] for r in range(world)]
+
+
+def _exchange(stage, make_blob, group=None, device=None):
+    """Runs `make_blob()` (this rank's stage work -> np.uint8 payload) and all-gathers the payloads. A rank whose work raised does NOT
+    leave the others blocked in the collective: every payload is prefixed with a status byte, the exception text travels in its place and
+    every rank raises the same RuntimeError after the exchange."""
+    import torch.distributed as dist
+    try:
+        payload, err = make_blob(), None
+    except Exception as e:              # noqa: BLE001 - whatever the stage raised must reach the other ranks as a message, not a hang
+        payload, err = np.frombuffer(("%s: %s" % (type(e).__name__, e)).encode("utf-8", "replace"), dtype=np.uint8), e
+    blob = np.concatenate([np.asarray([0 if err is None else 1], np.uint8), np.asarray(payload, np.uint8).reshape(-1)])
+    parts = _allgather_bytes(blob, group=group, device=device)
+    failed = [(r, bytes(b[1:]).decode("utf-8", "replace")) for r, b in enumerate(parts) if b[0] != 0]
+    if failed:
+        msg = "; ".join("rank %d: %s" % f for f in failed)
+        if err is not None:
+            raise RuntimeError("%s failed on %s" % (stage, msg)) from err
+        raise RuntimeError("%s failed on %s" % (stage, msg))
+    return [b[1:] for b in parts]
+
+
+def _npz_bytes(arrs):
+    import io
+    f = io.BytesIO()
+    np.savez(f, **arrs)
+    return np.frombuffer(f.getvalue(), dtype=np.uint8)
+
+
+def _npz_load(b):
+    import io
+    return np.load(io.BytesIO(np.asarray(b, np.uint8).tobytes()), allow_pickle=False)
 
 
 _SCENE_LISTS = ("prediction_list", "rgb_list", "vxl_ijk_list", "rayPooling_votes_list", "vxl_mask_list")
-_SCENE_ROWS = ("patches_embedding", "inScope_cubes_vs_views", "dissimilarity", "validCubes")            # one row per cube of the shard
-_SCENE_VALID_ROWS = ("viewPairs4Reconstr", "w_viewPairs4Reconstr")                                       # one row per VALID cube
+_SELECT_ROWS = ("patches_embedding", "inScope_cubes_vs_views", "dissimilarity")                          # one row per cube (intermediates)
 _SCENE_NONEMPTY_ROWS = ("cube_ijk_np", "param_np", "viewPair_np")                                        # one row per non-empty cube
 
 
-def _pack_scene(res):
-    """reconstruct_scene's dict -> one npz byte string (variable-length lists as a concatenation + lengths)."""
-    import io
+def _pack_lists(res):
+    """scene_cube_loop's dict -> one npz byte string (variable-length lists as a concatenation + lengths)."""
     arrs = {}
-    for k in _SCENE_ROWS + _SCENE_VALID_ROWS + _SCENE_NONEMPTY_ROWS:
+    for k in _SCENE_NONEMPTY_ROWS:
         if res.get(k) is not None:
             arrs[k] = np.asarray(res[k])
     for k in _SCENE_LISTS:
@@ -400,17 +499,14 @@ def _pack_scene(res):
         arrs[k + "/len"] = np.asarray([len(x) for x in lst], dtype=np.int64)
         if lst:
             arrs[k + "/cat"] = np.concatenate([np.asarray(x) for x in lst])
-    f = io.BytesIO()
-    np.savez(f, **arrs)
-    return np.frombuffer(f.getvalue(), dtype=np.uint8)
+    return _npz_bytes(arrs)
 
 
-def _merge_scenes(blobs):
-    """Per-rank npz byte strings (rank order = cube order) -> one reconstruct_scene dict."""
-    import io
-    parts = [np.load(io.BytesIO(b.tobytes()), allow_pickle=False) for b in blobs]
+def _merge_lists(blobs):
+    """Per-rank npz byte strings (rank order = valid-cube order) -> scene_cube_loop's dict for all valid cubes."""
+    parts = [_npz_load(b) for b in blobs]
     out = {}
-    for k in _SCENE_ROWS + _SCENE_VALID_ROWS + _SCENE_NONEMPTY_ROWS:
+    for k in _SCENE_NONEMPTY_ROWS:
         have = [p[k] for p in parts if k in p.files]
         out[k] = np.concatenate(have, axis=0) if have else None
     for k in _SCENE_LISTS:
@@ -423,19 +519,67 @@ def _merge_scenes(blobs):
     return out
 
 
-def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, *args, **kwargs):
-    """`reconstruct_scene` for a cube list sharded over the ranks of a torch.distributed process group (one process per GPU).
+def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, cube_D_mm=None, cube_D=None, N_viewPairs4inference=None, *args, **kwargs):
+    """`reconstruct_scene` over the ranks of a torch.distributed process group (one process per GPU; weights / images / cameras replicated).
 
-    Early rejection, view-pair selection, the cube loop and the thinning mask are all per-cube, and weights / images / cameras are
-    replicated, so rank r runs the whole single-GPU pipeline on its contiguous cube range `shard_bounds(N_cubes, world, r)` with
-    no data-path collective; at the end ONE exchange of each rank's packed result (sparse voxel lists: 9 B per kept voxel; per-cube
-    rows: embeddings, dissimilarities, selections) rebuilds on every rank exactly the dict `reconstruct_scene` returns for all
-    cubes (rank order = cube order). Keywords beside reconstruct_scene's: `group` (process group), `comm_device` (None: CPU tensors,
-    e.g. gloo; a CUDA device for RCCL), `shard_fn` (the per-shard pipeline; default `reconstruct_scene`)."""
+    Stage 1 - early rejection and view-pair selection (`scene_select`) - is sharded by RAW cube range: its cost is per cube (V patches each),
+    so contiguous ranges of the cube table balance it. Then ONE exchange of what stage 2 needs - the validCubes bits (1 bit per cube), the
+    selected pairs and weights of the valid cubes (N_vp x 20 B each) - gives every rank the scene's valid-cube list, and stage 2 - the cube loop
+    (`scene_cube_loop`: CVC, CNN, fusion, ray pooling, dense2sparse) - is sharded over THAT list (`main_reconstruct.py:126` batches over
+    `validCubes`): early rejection keeps 12 % of DTU scan9's cubes and they are spatially clustered, so a cut of the raw table
+    would leave most of the loop on a few ranks. A second exchange of the packed sparse lists (9 B per kept voxel) rebuilds on every rank
+    the dict `reconstruct_scene` returns (rank order = cube order). No data-path collective inside either stage.
+
+    Keywords beside reconstruct_scene's: `group`, `comm_device` (None: CPU tensors, e.g. gloo; a CUDA device for RCCL), `select_fn` / `loop_fn`
+    (stand-ins for the two stages, tests), `gather_intermediates` (False: the per-cube embeddings / dissimilarities - 25 KB per cube at 49
+    views, which no later stage needs - stay on the rank that computed them and the returned dict holds None for them).
+    A rank that raises inside a stage makes every rank raise after the next exchange (never a hang). The returned dict also carries
+    `cubes_per_rank` = [(raw cubes, valid cubes in the loop), ...]."""
     import torch.distributed as dist
     group, comm_device = kwargs.pop("group", None), kwargs.pop("comm_device", None)
-    shard_fn = kwargs.pop("shard_fn", None) or reconstruct_scene
+    select_fn, loop_fn = kwargs.pop("select_fn", None), kwargs.pop("loop_fn", None)
+    gather_intermediates = bool(kwargs.pop("gather_intermediates", False))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi = shard_bounds(len(cubes_param_np), world, rank)
-    res = shard_fn(images_list, cameraPOs_np, cubes_param_np[lo:hi], *args, **kwargs)
-    return _merge_scenes(_allgather_bytes(_pack_scene(res), group=group, device=comm_device))
+    N_cubes = len(cubes_param_np)
+    lo, hi = shard_bounds(N_cubes, world, rank)
+    if select_fn is None or loop_fn is None:
+        sel_kw, loop_kw = _scene_args(args, kwargs)
+    local = {}
+
+    def stage1():
+        sel = (select_fn(images_list, cameraPOs_np, cubes_param_np[lo:hi]) if select_fn is not None else
+               scene_select(images_list, cameraPOs_np, cubes_param_np[lo:hi], cube_D_mm, cube_D, N_viewPairs4inference, **sel_kw))
+        local.update(sel)
+        valid = np.asarray(sel["validCubes"], dtype=bool)
+        arrs = {"bits": np.packbits(valid), "n": np.asarray([valid.size], np.int64)}
+        if valid.any():
+            arrs["vp"], arrs["w"] = np.asarray(sel["viewPairs4Reconstr"]), np.asarray(sel["w_viewPairs4Reconstr"])
+        if gather_intermediates:
+            arrs.update({k: np.asarray(sel[k]) for k in _SELECT_ROWS})
+        return _npz_bytes(arrs)
+
+    parts = [_npz_load(b) for b in _exchange("early rejection / view-pair selection", stage1, group=group, device=comm_device)]
+    validCubes = np.concatenate([np.unpackbits(p["bits"])[: int(p["n"][0])].astype(bool) for p in parts]) if N_cubes else np.zeros((0,), bool)
+    have = [p for p in parts if "vp" in p.files]
+    out = dict(validCubes=validCubes, viewPairs4Reconstr=None, w_viewPairs4Reconstr=None)
+    for k in _SELECT_ROWS:
+        out[k] = np.concatenate([p[k] for p in parts], axis=0) if gather_intermediates else None
+    n_valid = int(validCubes.sum())
+    per_rank_raw = [int(p["n"][0]) for p in parts]
+    if n_valid == 0:
+        out.update({k: (list(v) if isinstance(v, list) else v) for k, v in _LOOP_EMPTY.items()})
+        out["cubes_per_rank"] = [(r, 0) for r in per_rank_raw]
+        return out
+    vp, w = np.concatenate([p["vp"] for p in have], axis=0), np.concatenate([p["w"] for p in have], axis=0)
+    out.update(viewPairs4Reconstr=vp, w_viewPairs4Reconstr=w)
+    valid_rows = cubes_param_np[validCubes]
+    vlo, vhi = shard_bounds(n_valid, world, rank)                     # contiguous ranges of the VALID list: equal to within one cube
+
+    def stage2():
+        res = (loop_fn(images_list, cameraPOs_np, valid_rows[vlo:vhi], vp[vlo:vhi], w[vlo:vhi]) if loop_fn is not None else
+               scene_cube_loop(images_list, cameraPOs_np, valid_rows[vlo:vhi], vp[vlo:vhi], w[vlo:vhi], cube_D, N_viewPairs4inference, **loop_kw))
+        return _pack_lists(res)
+
+    out.update(_merge_lists(_exchange("cube loop", stage2, group=group, device=comm_device)))
+    out["cubes_per_rank"] = [(per_rank_raw[r], shard_bounds(n_valid, world, r)[1] - shard_bounds(n_valid, world, r)[0]) for r in range(world)]
+    return out

@@ -37,8 +37,22 @@ def set_simil_param_values(values):
         ctx.load_simil_param_values(values)
 
 
+_preferred_cube_D = None
+
+
+def prefer_cube_D(cube_D):
+    """Tells the runtime which cube size the scene at hand will use (SurfaceNet_inference(cube_D=...) and reconstruct_scene call this),
+    so that cube-size independent work that comes first (projections, patch cropping, the similarityNet) lands in THAT context instead
+    of creating a second one - with its own workspace and its own copy of the images - for the default size."""
+    global _preferred_cube_D
+    _preferred_cube_D = None if cube_D is None else int(cube_D)
+
+
 def any_context():
-    """A context for work that does not depend on cube_D (similarityNet, patch cropping)."""
+    """A context for work that does not depend on cube_D (projections, similarityNet, patch cropping): the preferred size's context
+    (prefer_cube_D), else any live one, else a new one of the smaller size."""
+    if _preferred_cube_D is not None:
+        return context_for(_preferred_cube_D)
     for ctx in _contexts.values():
         return ctx
     return context_for(32)        # cube-size independent work: the smaller workspace
@@ -134,6 +148,8 @@ def bind_cameras(ctx, cameraPOs):
 
 
 def reset():
+    global _preferred_cube_D
+    _preferred_cube_D = None
     for ctx in _contexts.values():
         ctx.close()
     _contexts.clear()

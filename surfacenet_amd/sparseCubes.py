@@ -42,32 +42,31 @@ def dense2sparse(prediction, rgb, param, viewPair, min_prob=0.5, rayPool_thresh=
     return nonempty, cut(ijk), cut(p16), cut(rgb_out), (cut(votes) if enable_rayPooling else []), param_new
 
 
+def _grow(table, rows):
+    """A running per-cube table (None before the first batch) with the batch's rows appended along axis 0."""
+    return rows if table is None else np.concatenate([table, rows], axis=0)
+
+
 def append_dense_2sparseList(prediction_sub, rgb_sub, param_sub, viewPair_sub, min_prob=0.5, rayPool_thresh=0, enable_centerCrop=False,
                              cube_Dcenter=None, enable_rayPooling=False, cameraPOs=None, cameraTs=None, prediction_list=[],
                              rgb_list=[], vxl_ijk_list=[], rayPooling_votes_list=[], cube_ijk_np=None, param_np=None, viewPair_np=None):
-    """utils/sparseCubes.py:82-160: casts, dense2sparse, then appends to the running lists / arrays (lists are extended in
-    place, as in the reference). prediction_sub (N,1,D,D,D)/(N,D,D,D), rgb_sub (N,3,D,D,D)."""
-    prediction_sub = np.asarray(prediction_sub)
-    if prediction_sub.ndim == 5:
-        prediction_sub = prediction_sub.astype(np.float16)[:, 0]
-    rgb_sub = np.transpose(np.asarray(rgb_sub).astype(np.uint8), axes=(0, 2, 3, 4, 1))
-    cube_ijk_sub = param_sub['ijk']
-    viewPair_sub = np.asarray(viewPair_sub).astype(np.uint16)
-    nonempty, vxl_ijk_sub_list, prediction_sub_list, rgb_sub_list, votes_sub_list, param_new_sub = dense2sparse(
-        prediction=prediction_sub, rgb=rgb_sub, param=param_sub, viewPair=viewPair_sub, min_prob=min_prob, rayPool_thresh=rayPool_thresh,
-        enable_centerCrop=enable_centerCrop, cube_Dcenter=cube_Dcenter, enable_rayPooling=enable_rayPooling, cameraPOs=cameraPOs,
-        cameraTs=cameraTs)
-    param_sub = param_new_sub[nonempty]
-    viewPair_sub = viewPair_sub[nonempty]
-    cube_ijk_sub = cube_ijk_sub[nonempty]
-    prediction_list.extend(prediction_sub_list)
-    rgb_list.extend(rgb_sub_list)
-    vxl_ijk_list.extend(vxl_ijk_sub_list)
-    rayPooling_votes_list.extend(votes_sub_list)
-    param_np = param_sub if param_np is None else np.concatenate([param_np, param_sub], axis=0)
-    viewPair_np = viewPair_sub if viewPair_np is None else np.vstack([viewPair_np, viewPair_sub])
-    cube_ijk_np = cube_ijk_sub if cube_ijk_np is None else np.vstack([cube_ijk_np, cube_ijk_sub])
-    return prediction_list, rgb_list, vxl_ijk_list, rayPooling_votes_list, cube_ijk_np, param_np, viewPair_np
+    """One batch of the loop body's bookkeeping (call site main_reconstruct.py:154-162; contract of utils/sparseCubes.py:82-160): the dense
+    batch - prediction_sub (N,1,D,D,D) or (N,D,D,D), rgb_sub (N,3,D,D,D) - goes through `dense2sparse` on the GPU and what survives is
+    appended to the caller's running state: the four voxel lists are extended IN PLACE (the reference's callers rely on that), the three
+    per-cube tables (cube ijk, cube parameters with the cropped origin, view pairs as uint16) grow by the batch's non-empty cubes and are
+    returned. Returns (prediction_list, rgb_list, vxl_ijk_list, rayPooling_votes_list, cube_ijk_np, param_np, viewPair_np)."""
+    pred = np.asarray(prediction_sub)
+    if pred.ndim == 5:                                   # (N,1,D,D,D) float32 from the network -> the float16 (N,D,D,D) the sparse lists store
+        pred = pred.astype(np.float16)[:, 0]
+    colours = np.moveaxis(np.asarray(rgb_sub).astype(np.uint8), 1, -1)          # channels last, as dense2sparse indexes them
+    pairs16 = np.asarray(viewPair_sub).astype(np.uint16)
+    keep, ijk_b, pred_b, rgb_b, votes_b, param_cropped = dense2sparse(
+        prediction=pred, rgb=colours, param=param_sub, viewPair=pairs16, min_prob=min_prob, rayPool_thresh=rayPool_thresh,
+        enable_centerCrop=enable_centerCrop, cube_Dcenter=cube_Dcenter, enable_rayPooling=enable_rayPooling, cameraPOs=cameraPOs, cameraTs=cameraTs)
+    for running, batch in ((prediction_list, pred_b), (rgb_list, rgb_b), (vxl_ijk_list, ijk_b), (rayPooling_votes_list, votes_b)):
+        running.extend(batch)
+    return (prediction_list, rgb_list, vxl_ijk_list, rayPooling_votes_list,
+            _grow(cube_ijk_np, param_sub['ijk'][keep]), _grow(param_np, param_cropped[keep]), _grow(viewPair_np, pairs16[keep]))
 
 
 def filter_voxels(vxl_mask_list=[], prediction_list=None, prob_thresh=None, rayPooling_votes_list=None, rayPool_thresh=None):

@@ -28,9 +28,15 @@ def test_header_binding_and_library_agree(built):
     lib = built.load()
     for name in hdr:
         assert hasattr(lib, name), name
+    # the header IS the dynamic symbol table: the library is built with -fvisibility=hidden, so nothing else - C++ internals (pack_conv, rccl
+    # glue), kernel host stubs, the sn_debug_* test hooks - may be exported by the product .so
     out = subprocess.check_output(["nm", "-D", "--defined-only", built.LIB_PATH]).decode()
-    exported = set(re.findall(r" T (sn_[a-z0-9_]+)", out))
-    assert set(hdr) <= exported
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == hdr, sorted(set(exported) ^ set(hdr))
+    dbg = os.path.join(os.path.dirname(built.LIB_PATH), "libsurfacenet_hip_dbg.so")       # the test-only twin: the same ABI + the hooks
+    out = subprocess.check_output(["nm", "-D", "--defined-only", dbg]).decode()
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert set(hdr) <= set(exported) and set(exported) - set(hdr) == {"sn_debug_tensor", "sn_debug_mx6_encode", "sn_debug_timing", "sn_debug_trace"}
 
 
 def test_version_and_no_gpu_fails_loudly(built):
@@ -76,7 +82,7 @@ def test_host_mx6_encoder_matches_the_format(built, fmt):
     """The weight packer's 6-bit encoder (sn_api.hip mx6_encode): exact on every representable value, round-to-nearest-even on the
     midpoints, saturating, monotone - the properties the device-side conversions have (fp6_probe) and the CPU model assumes."""
     import ctypes
-    lib = built.load()
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(built.LIB_PATH), "libsurfacenet_hip_dbg.so"))      # hooks live in the test-only twin
     enc = lib.sn_debug_mx6_encode
     enc.restype = ctypes.c_int
     enc.argtypes = [ctypes.c_float, ctypes.c_int]

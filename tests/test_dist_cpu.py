@@ -99,31 +99,51 @@ def test_sparse_lists_exchange_gloo(n):
 PARAM_DT = [("xyz", np.float32, (3,)), ("ijk", np.uint32, (3,)), ("resol", np.float32)]
 
 
-def _fake_scene(images_list, cameraPOs_np, cubes, *a, **kw):
-    """Stand-in for the per-shard GPU pipeline with reconstruct_scene's return contract: everything is a deterministic function of
-    the cube's 'ijk' tag, so a sharded run must reproduce the one-piece run bit for bit. Cube g is rejected when g % 4 == 3 and
-    yields no voxels when g % 5 == 0."""
+def _fake_select(images_list, cameraPOs_np, cubes, valid_rule=None):
+    """Stand-in for stage 1 (scene_select: early rejection + view-pair selection) with its return contract: everything is a deterministic
+    function of the cube's 'ijk' tag, so a sharded run must reproduce the one-piece run bit for bit. Cube g is rejected when g % 4 == 3
+    (or by `valid_rule`)."""
     g = cubes["ijk"][:, 0].astype(np.int64)
     n, V, N_vp = len(cubes), 3, 2
     rs = lambda i: np.random.RandomState(int(i))
     emb = np.stack([rs(i).rand(V, 8).astype(np.float32) for i in g]) if n else np.zeros((0, V, 8), np.float32)
-    valid = (g % 4) != 3
-    out = dict(patches_embedding=emb, inScope_cubes_vs_views=(emb[:, :, 0] > 0.2), dissimilarity=emb[:, :, 1].copy(), validCubes=valid,
-               prediction_list=[], rgb_list=[], vxl_ijk_list=[], rayPooling_votes_list=[], cube_ijk_np=None, param_np=None, viewPair_np=None,
+    valid = ((g % 4) != 3) if valid_rule is None else valid_rule(g)
+    out = dict(patches_embedding=emb, inScope_cubes_vs_views=(emb[:, :, 0] > 0.2), dissimilarity=emb[:, :, 1].copy(), validCubes=valid)
+    if valid.any():
+        gv = g[valid]
+        out["viewPairs4Reconstr"] = np.stack([rs(100 + i).randint(0, V, (N_vp, 2)) for i in gv])
+        out["w_viewPairs4Reconstr"] = np.stack([rs(200 + i).rand(N_vp).astype(np.float32) for i in gv])
+    return out
+
+
+def _fake_loop(images_list, cameraPOs_np, valid_cubes, vp, w):
+    """Stand-in for stage 2 (scene_cube_loop) on a run of valid cubes: cube g yields no voxels when g % 5 == 0."""
+    out = dict(prediction_list=[], rgb_list=[], vxl_ijk_list=[], rayPooling_votes_list=[], cube_ijk_np=None, param_np=None, viewPair_np=None,
                vxl_mask_list=[])
-    if not valid.any():
+    if len(valid_cubes) == 0:
         return out
-    gv = g[valid]
-    out["viewPairs4Reconstr"] = np.stack([rs(100 + i).randint(0, V, (N_vp, 2)) for i in gv])
-    out["w_viewPairs4Reconstr"] = np.stack([rs(200 + i).rand(N_vp).astype(np.float32) for i in gv])
+    rs = lambda i: np.random.RandomState(int(i))
+    gv = valid_cubes["ijk"][:, 0].astype(np.int64)
+    assert np.array_equal(vp, np.stack([rs(100 + i).randint(0, 3, (2, 2)) for i in gv]))      # the selections travelled with their cubes
     keep = [j for j, i in enumerate(gv) if i % 5]
     for j in keep:
         i, k = gv[j], int(gv[j] % 7) + 1
         out["prediction_list"].append(rs(300 + i).rand(k).astype(np.float16)); out["rgb_list"].append(rs(400 + i).randint(0, 256, (k, 3)).astype(np.uint8))
         out["vxl_ijk_list"].append(rs(500 + i).randint(0, 26, (k, 3)).astype(np.uint8)); out["rayPooling_votes_list"].append(rs(600 + i).randint(0, 5, k).astype(np.uint8))
         out["vxl_mask_list"].append(rs(700 + i).rand(k) > 0.5)
-    sub = cubes[valid][keep]
-    out.update(param_np=sub, cube_ijk_np=sub["ijk"], viewPair_np=out["viewPairs4Reconstr"].astype(np.uint16)[keep])
+    sub = valid_cubes[keep]
+    out.update(param_np=sub, cube_ijk_np=sub["ijk"], viewPair_np=np.asarray(vp).astype(np.uint16)[keep])
+    return out
+
+
+def _fake_scene(images_list, cameraPOs_np, cubes, valid_rule=None):
+    """The one-piece run: stage 1 on all cubes, stage 2 on all valid cubes."""
+    out = _fake_select(images_list, cameraPOs_np, cubes, valid_rule)
+    v = out["validCubes"]
+    if v.any():
+        out.update(_fake_loop(images_list, cameraPOs_np, cubes[v], out["viewPairs4Reconstr"], out["w_viewPairs4Reconstr"]))
+    else:
+        out.update(_fake_loop(images_list, cameraPOs_np, cubes[:0], None, None))
     return out
 
 
@@ -135,7 +155,11 @@ def _scene_cubes(n):
     return cubes
 
 
-def _scene_worker(rank, world, port, n, q):
+def _clustered(g):
+    return g >= 13                                   # every valid cube lies in the LAST raw shard of a 2-rank cut of 20 cubes
+
+
+def _scene_worker(rank, world, port, n, mode, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -143,14 +167,29 @@ def _scene_worker(rank, world, port, n, q):
     import test_dist_cpu as T
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = reconstruct.reconstruct_scene_sharded([], np.zeros((3, 3, 4)), T._scene_cubes(n), shard_fn=T._fake_scene)
-    q.put((rank, res))
+    counts = []
+
+    def loop_fn(imgs, P, valid_cubes, vp, w):
+        counts.append(len(valid_cubes))
+        if mode == "raise" and rank == 1:
+            raise ValueError("SN_ERR_RANGE stand-in on rank 1")
+        return T._fake_loop(imgs, P, valid_cubes, vp, w)
+
+    rule = T._clustered if mode == "clustered" else None
+    try:
+        res = reconstruct.reconstruct_scene_sharded([], np.zeros((3, 3, 4)), T._scene_cubes(n), select_fn=lambda i, P, c: T._fake_select(i, P, c, rule),
+                                                    loop_fn=loop_fn, gather_intermediates=(mode != "lean"))
+        q.put((rank, res, counts))
+    except RuntimeError as e:
+        q.put((rank, "RuntimeError: %s" % e, counts))
     dist.destroy_process_group()
 
 
-def _same_scene(a, b):
-    for k in ("patches_embedding", "inScope_cubes_vs_views", "dissimilarity", "validCubes", "viewPairs4Reconstr", "w_viewPairs4Reconstr",
-              "cube_ijk_np", "param_np", "viewPair_np"):
+def _same_scene(a, b, intermediates=True):
+    keys = ("validCubes", "viewPairs4Reconstr", "w_viewPairs4Reconstr", "cube_ijk_np", "param_np", "viewPair_np")
+    if intermediates:
+        keys += ("patches_embedding", "inScope_cubes_vs_views", "dissimilarity")
+    for k in keys:
         x, y = a.get(k), b.get(k)
         assert (x is None) == (y is None), k
         assert x is None or (np.array_equal(x, y) and x.dtype == y.dtype), k
@@ -158,21 +197,53 @@ def _same_scene(a, b):
         assert len(a[k]) == len(b[k]) and all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(a[k], b[k])), k
 
 
-@pytest.mark.parametrize("n", [11, 3, 1])
-def test_sharded_scene_equals_one_piece_gloo(n):
-    """reconstruct_scene_sharded over 2 ranks (contiguous cube shards, one exchange of the packed results) == the one-piece run;
-    n = 1 leaves rank 1 with an empty shard, n = 3 gives rank 1 a shard whose only cube is rejected / empty."""
+def _run_scene_ranks(n, mode, port_base):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() + n) % 2000
-    procs = [ctx.Process(target=_scene_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    port = port_base + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_scene_worker, args=(r, 2, port, n, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("n", [11, 3, 1])
+def test_sharded_scene_equals_one_piece_gloo(n):
+    """reconstruct_scene_sharded over 2 ranks (stage 1 on contiguous raw cube shards, exchange of the valid bits + selections, stage 2 on
+    contiguous shards of the VALID list, exchange of the packed sparse lists) == the one-piece run; n = 1 leaves rank 1 with an empty
+    raw shard, n = 3 gives rank 1 a raw shard whose only cube is rejected."""
     want = _fake_scene([], None, _scene_cubes(n))
-    for rank, full in res:
+    for rank, full, counts in _run_scene_ranks(n, "full", 33500):
         _same_scene(full, want)
+
+
+def test_sharded_scene_balances_the_valid_list_gloo():
+    """SURVEY §8(e) / main_reconstruct.py:126: the cube loop is partitioned over the VALID cubes. 20 cubes whose 7 valid ones all lie in rank
+    1's raw shard: a cut of the raw table would give rank 0 nothing; the per-rank loop counts must differ by at most one. Also the lean
+    exchange (no per-cube intermediates) returns None for them and everything else unchanged."""
+    want = _fake_scene([], None, _scene_cubes(20), _clustered)
+    assert int(want["validCubes"].sum()) == 7 and not want["validCubes"][:13].any()
+    for mode in ("clustered",):
+        res = _run_scene_ranks(20, mode, 35500)
+        per_rank = [c for _, _, c in res]
+        assert sorted(sum(c) for c in per_rank) == [3, 4], per_rank
+        for rank, full, counts in res:
+            _same_scene(full, want)
+            assert full["cubes_per_rank"] == [(10, 4), (10, 3)]
+    want = _fake_scene([], None, _scene_cubes(9))
+    for rank, full, counts in _run_scene_ranks(9, "lean", 37500):
+        _same_scene(full, want, intermediates=False)
+        assert full["patches_embedding"] is None and full["dissimilarity"] is None
+
+
+def test_sharded_scene_failure_on_one_rank_raises_everywhere_gloo():
+    """A rank whose stage raises (SN_ERR_RANGE, a ray-pooling error ...) must not leave the others blocked in the all-gather: the exception
+    text travels in the exchange and EVERY rank raises."""
+    res = _run_scene_ranks(11, "raise", 39500)
+    for rank, full, counts in res:
+        assert isinstance(full, str) and "cube loop failed on rank 1" in full and "SN_ERR_RANGE stand-in" in full, full

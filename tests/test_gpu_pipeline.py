@@ -106,8 +106,9 @@ def _run_scene(inp, sharded):
     p2e, pair_fn = similarityNet.similarityNet_inference(None, (64, 64), param_values=inp["simil_values"])
     relw_fn, _ = SurfaceNet.SurfaceNet_inference(inp["N_vp"], None, None, cube_D=inp["cube_D"], param_values=inp["net_values"])
     fn = reconstruct.reconstruct_scene_sharded if sharded else reconstruct.reconstruct_scene
+    extra = dict(gather_intermediates=True) if sharded else {}      # the test compares the per-cube embeddings / dissimilarities too
     res = fn(inp["imgs"], inp["P"], inp["cubes"], inp["cube_D_mm"], inp["cube_D"], inp["N_vp"], p2e, pair_fn, relw_fn, cube_Dcenter=inp["Dc"],
-             patches_mean_bgr=MEAN_BGR, batchSize_nViewPair_SurfaceNet=4, min_prob=0.5, tau=0.6, gamma=0.5)
+             patches_mean_bgr=MEAN_BGR, batchSize_nViewPair_SurfaceNet=4, min_prob=0.5, tau=0.6, gamma=0.5, **extra)
     runtime.reset()
     return res
 
@@ -127,8 +128,9 @@ def _sharded_worker(rank, world, port, q):
 
 
 def test_sharded_scene_two_processes_equals_single_process(gpu_required):
-    """reconstruct_scene_sharded with 2 ranks (two processes on this box's GPU, cube shards 0-5 / 6-11, gloo exchange) returns on
-    every rank exactly what the single-process reconstruct_scene returns - GPU kernels on both sides."""
+    """reconstruct_scene_sharded with 2 ranks (two processes on this box's GPU, gloo exchange; early rejection + selection on the raw cube
+    shards 0-5 / 6-11, the cube loop on halves of the VALID list) returns on every rank exactly what the single-process reconstruct_scene
+    returns - the real GPU pipeline in both stages on both ranks."""
     import os
     import torch.multiprocessing as mp
     import test_dist_cpu
@@ -144,8 +146,10 @@ def test_sharded_scene_two_processes_equals_single_process(gpu_required):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    n_valid = int(want["validCubes"].sum())
     for rank, full in res:
         test_dist_cpu._same_scene(full, want)
+        assert full["cubes_per_rank"] == [(6, n_valid - n_valid // 2), (6, n_valid // 2)]        # the loop is cut over the valid list, to within one cube
 
 
 def test_marked_readback_sees_its_own_batch(gpu_required):

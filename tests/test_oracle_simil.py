@@ -104,3 +104,9 @@ def test_camera_centres_doctest():
     assert np.allclose(camera_centers(P[None])[0], t)
     assert camera_centers([P, P]).shape == (2, 3)
     assert np.allclose(P @ np.r_[camera_centers(P)[0], 1.0], 0, atol=1e-6)
+    # the drop-in's cameraPs2Ts keeps the reference's container contract (utils/camera.py:103-120): list in -> list out, array in -> array out
+    from surfacenet_amd import camera
+    as_list = camera.cameraPs2Ts([P, 2 * P])
+    assert type(as_list) is list and len(as_list) == 2 and as_list[0].shape == (3,) and np.allclose(as_list[0], t) and np.allclose(as_list[1], t)
+    as_arr = camera.cameraPs2Ts(np.stack([P, P]))
+    assert isinstance(as_arr, np.ndarray) and as_arr.shape == (2, 3) and np.allclose(as_arr, t)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--with-simil", action="store_true", help="also run bench.py's similarityNet leg (patches/s)")
     ap.add_argument("--extra", default="", help="extra bench.py arguments, e.g. '--precision f16'")
     ap.add_argument("--keys", default="merge_conv_b,merge_conv_a,conv1_2,conv2_2,conv3_2,conv4_2,side_op234_deconv")
     ap.add_argument("variants", nargs="+")
@@ -37,9 +38,14 @@ def main():
     keys = args.keys.split(",")
     if args.check:
         outs = []
-        for name, lib in variants:
+        for name, lib in list(variants):
             out = "/tmp/ab_%s.npz" % name
-            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ab_outputs.py"), "save", out], env=dict(os.environ, SURFACENET_HIP_LIB=lib))
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab_outputs.py"), "save", out], env=dict(os.environ, SURFACENET_HIP_LIB=lib),
+                               capture_output=True, text=True)
+            if p.returncode != 0:
+                print("== %s FAILS the output check and is dropped:\n%s" % (name, p.stderr[-600:]), flush=True)
+                variants.remove((name, lib))
+                continue
             outs.append(out)
         for (name, _), out in zip(variants[1:], outs[1:]):
             print("== outputs of %s vs %s" % (name, variants[0][0]), flush=True)
@@ -48,7 +54,7 @@ def main():
     for r in range(args.rounds):
         for name, lib in variants:
             cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup", "3", "--no-fast-mode", "--no-cpu-baseline", "--no-s64",
-                   "--no-simil", "--no-post-pass", "--no-scenes"] + args.extra.split()
+                   "--no-post-pass", "--no-scenes"] + ([] if args.with_simil else ["--no-simil"]) + args.extra.split()
             p = subprocess.run(cmd, env=dict(os.environ, SURFACENET_HIP_LIB=lib), capture_output=True, text=True)
             if p.returncode != 0:
                 print("%s: bench.py failed:\n%s" % (name, p.stderr[-2000:]), flush=True)
@@ -56,7 +62,8 @@ def main():
             j = json.loads(p.stdout.strip().splitlines()[-1])
             k = j["kernels_ms_per_step"]
             res[name].append((j["value"], [k.get(x, float("nan")) for x in keys]))
-            print("round %d %-12s %8.1f cubes/s  %s" % (r, name, j["value"], "  ".join("%s %.3f" % (x, k.get(x, float("nan"))) for x in keys)), flush=True)
+            sim = ("  simil %.0f patches/s (s_conv1_2 %.3f ms)" % (j["similarity_net"]["value"], j["similarity_net"]["kernels_ms_per_step"].get("s_conv1_2", float("nan")))) if "similarity_net" in j else ""
+            print("round %d %-12s %8.1f cubes/s  %s%s" % (r, name, j["value"], "  ".join("%s %.3f" % (x, k.get(x, float("nan"))) for x in keys), sim), flush=True)
     print("== medians")
     for name, _ in variants:
         if not res[name]:

@@ -7,7 +7,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME="$1"; shift
 OUT="$ROOT/gpurun_abl/$NAME"
 mkdir -p "$OUT"
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function $*"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -DSN_DEBUG_HOOKS -Wall -Wno-unused-function $*"
 cd "$ROOT/surfacenet_amd/csrc"
 pids=()
 for f in sn_api sn_post sn_simil; do
@@ -15,6 +15,6 @@ for f in sn_api sn_post sn_simil; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT/libsurfacenet_hip.so" "$OUT"/sn_api.o "$OUT"/sn_post.o "$OUT"/sn_simil.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -Wl,--version-script=exports.map -o "$OUT/libsurfacenet_hip.so" "$OUT"/sn_api.o "$OUT"/sn_post.o "$OUT"/sn_simil.o
 rm -f "$OUT"/*.o
 echo "$OUT/libsurfacenet_hip.so  [$*]"
