@@ -99,9 +99,9 @@ def fast_mode(surfacenet_amd, scene, values, s, n, n_vp, device, steps):
             "note": "operands rounded to fp16: L_inf vs fp64 oracle 1e-3..4e-3 on BN-calibrated nets (above the 1e-3 bar) - not the headline"}
 
 
-def s64_mode(surfacenet_amd, values, n_vp, device, steps, precision, n=8):
-    """Extra, non-headline measurement: the same hot path at s=64 (params.py:65 __cube_D = 64), n cubes x n_vp pairs per step
-    (8 x 2 x 64^3 voxels = the voxel count of the headline workload)."""
+def s64_mode(surfacenet_amd, values, n_vp, device, steps, precision, n=32):
+    """Extra, non-headline measurement: one GPU's shard of BASELINE.json configs[3] - s=64 (params.py:65 __cube_D = 64), batch 256 over 8 GPUs =
+    32 cubes x n_vp view pairs per step and GPU (4x the voxel count of the headline step; 21 GB of activation workspace)."""
     s = 64
     scene = synthetic.synthetic_scene(n, n_vp, s=s, seed=0)
     ctx = surfacenet_amd.Context(cube_D=s, max_samples=n * n_vp, device=device, precision=precision)
@@ -123,6 +123,7 @@ def s64_mode(surfacenet_amd, values, n_vp, device, steps, precision, n=8):
     dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
     ach = prof[dom]["flops"] / (prof[dom]["ms"] * 1e-3) / 1e12
     return {"value": round(n * steps / el, 2), "unit": "cubes/s (s=64)", "ms_per_step": round(el / steps * 1e3, 3), "cubes_per_step": n, "n_vp": n_vp,
+            "workload": "one GPU's shard of BASELINE.json configs[3]: s=64, 256 cubes over 8 GPUs = %d cubes x %d view pairs per step" % (n, n_vp),
             "equivalent_s32_cubes_per_s": round(8 * n * steps / el, 1),
             "roofline": {"bound": "mfma", "kernel": "conv3d_f16_mfma<%s>" % dom, "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4)}}
@@ -370,7 +371,13 @@ def main():
             "end_to_end_tflops": round(cubes_per_s / world * n_vp * CNN_FLOPS_PER_SAMPLE_S32 * (s / 32.0) ** 3 / 1e12, 2),
         }
         if cvc:
-            out["cvc_warp"] = {"bound": "hbm", "achieved_GBps": round(cvc["bytes"] / (cvc["ms"] * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
+            # 2 views x s^3 x 3 B gathered + 6 x s^3 x 4 B of planar fp32 written per cube-view-pair = 983,040 B at s = 32. The launch
+            # measured here is the FUSED form (writes conv1_1's fp16 hi/lo input instead of the planar tensor): its own traffic is `bytes_per_launch_fused_form`
+            survey_bytes = (2 * 3 + 6 * 4) * s3 * n * n_vp
+            t_cvc = cvc["ms"] / cvc["launches"] * 1e-3
+            out["cvc_warp"] = {"bound": "hbm", "achieved_GBps": round(survey_bytes / t_cvc / 1e9, 1), "peak_GBps": 8000.0, "frac": round(survey_bytes / t_cvc / 8e12, 4),
+                               "bytes_per_launch": survey_bytes, "bytes_basis": "SURVEY 8(d): 983,040 B per cube-view-pair at s=32 (planar fp32 form)",
+                               "achieved_GBps_fused_form": round(cvc["bytes"] / (cvc["ms"] * 1e-3) / 1e9, 1), "bytes_per_launch_fused_form": cvc["bytes"] / cvc["launches"],
                                "avg_launch_ms": round(cvc["ms"] / cvc["launches"], 4)}
         out["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         out["profiled_loop_ms_per_step"] = round(elapsed_prof / args.steps * 1e3, 3)     # same K steps with the per-kernel events on

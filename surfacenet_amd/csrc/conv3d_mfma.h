@@ -107,10 +107,13 @@
                           // 3..6 (f16m8 kernels): the two wait slots hold segment times of a weight piece instead, see the piece loop
 #endif
 #ifndef SN_PP
-#define SN_PP 0           // 1: ping-pong K loop for the f16m8 3x3x3 kernels (merge_conv_a / merge_conv_b), see the slab loop
+#define SN_PP 1           // 1: ping-pong K loop for the f16m8 3x3x3 kernels (merge_conv_a / merge_conv_b), see the slab loop
 #endif
 #ifndef SN_PPX
-#define SN_PPX 0          // 1: ping-pong K loop for the f16 / f16x3 3x3 kernels with at least two K-chunks per weight piece
+#define SN_PPX 1          // 1: ping-pong K loop for the f16 / f16x3 3x3 kernels with at least two K-chunks per weight piece
+#endif
+#ifndef SN_PPX_SEGC
+#define SN_PPX_SEGC 1     // 2: two K-chunks per ping-pong segment where a chunk is a short burst (MF * NF <= 8: conv1_x)
 #endif
 #ifndef SN_PP_MERGE
 #define SN_PP_MERGE 0     // ping-pong: the two f16 chunks of a weight piece form ONE segment (2 * MF * NF MFMAs per burst, one barrier pair less per piece)
@@ -119,7 +122,7 @@
 #define SN_PP_WPRE 0      // ping-pong: the MX step's weight fragments are read in the load segments of the f16 chunks (1: all with the second, 2: split)
 #endif
 #ifndef SN_PP_WIN
-#define SN_PP_WIN 0       // ping-pong: the next segment's weight fragments are read from inside the MFMA burst (see compute_f16)
+#define SN_PP_WIN 1       // ping-pong: the next segment's weight fragments are read from inside the MFMA burst (see compute_f16); 1: EPI_FINAL kernels, 2: all
 #endif
 #ifndef SN_PP_WSPLIT
 #define SN_PP_WSPLIT 1    // SN_PP_WIN: weight DMA instalments issued with chunk 2p (the rest with chunk 2p+1, whose load segment is short)
@@ -137,7 +140,7 @@
 #define SN_PP_EARLYBAR 0  // ping-pong: a slot's closing barrier in front of the burst's last MF MFMAs instead of behind them
 #endif
 #ifndef SN_PP_B128
-#define SN_PP_B128 0      // ping-pong MX segment: read the activation code slots whole (ds_read_b128) instead of their 12 code bytes (ds_read_b96)
+#define SN_PP_B128 1      // ping-pong MX segment: read the activation code slots whole (ds_read_b128) instead of their 12 code bytes (ds_read_b96)
 #endif
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
@@ -643,26 +646,30 @@ conv3d_f16_mfma(ConvArgs a)
 
             if constexpr (PPX) {
                 // ---- PING-PONG K loop, f16 / f16x3 kernels (round 3) ---------------------------------------------------
-                // Same structure as the f16m8 loop below: a segment = one K-chunk; its NPLM * (MF + NF) operand fragments are read into registers in the
-                // wave's LOAD slot (with the tap offset of the next chunk and the wave's DMA duties), its (SPLIT ? 3 : 1) * MF * NF MFMAs run as one
-                // uninterrupted burst in its COMPUTE slot; wave group 1 runs one barrier behind group 0, so each SIMD's matrix pipe always
-                // belongs to exactly one wave. MFMA order per chunk = the software-pipelined loop's, so results are bit-identical to it.
-                // DMA duties: the next weight piece with the first chunk of a piece, the next slab's halo tile with the second chunk of a slab's
-                // first piece, the wait for the weights with the piece's last chunk (the halo, younger, may stay in flight: counted wait).
+                // Same structure as the f16m8 loop below: a segment = SEGC K-chunks; their NPLM * (MF + NF) operand fragments each are read into
+                // registers in the wave's LOAD slot (with the tap offsets of the next segment and the wave's DMA duties), their (SPLIT ? 3 : 1) * MF * NF
+                // MFMAs each run as one uninterrupted burst in its COMPUTE slot; wave group 1 runs one barrier behind group 0, so each SIMD's matrix
+                // pipe always belongs to exactly one wave. MFMA order per chunk = the software-pipelined loop's, so results are bit-identical to it.
+                // DMA duties: the next weight piece with the first segment of a piece, the next slab's halo tile with the second segment of a slab's
+                // first piece, the wait for the weights with the piece's last segment (the halo, younger, may stay in flight: counted wait).
+                // (tried, A/B r3j: the next slab's halo DMAs dealt out one or two per load segment instead of all HT in one - conv1_x +27 %,
+                // conv4_x +12 %, similarityNet -12 %: a load segment that carries any DMA pays for its set-up, and most of them are on the critical path)
                 static_assert(C::PCH >= 2 && BUFH && SPLIT != 2, "ping-pong loop (f16 / f16x3): at least two chunks per weight piece");
+                // SEGC = 2 where a chunk is a short burst (conv1_x: 24 MFMAs): halves the barriers per MFMA
+                constexpr int SEGC = (SN_PPX_SEGC == 2 && MF * NF <= 8 && C::PCH >= 3) ? 2 : 1;
+                constexpr int NSEGMAX = (C::PCH + SEGC - 1) / SEGC;
                 const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
                 const unsigned xslab = xbuf_a + xb * C::XBUF;
                 constexpr int NPLM = C::NPLM;
-                int ko, ko_n = 0;
-                lds_read32<0>(ko, koff_a);
+                int ko[SEGC], ko_n[SEGC];
+                static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_read32<j * 16>(ko[j], koff_a); ko_n[j] = 0; });
                 lgkm_wait<0>();
-                constexpr int WCNT = C::PCH * NF * NPL;                     // 1 KiB DMAs per (full) weight piece
-                constexpr int WPW = (WCNT + C::NW - 1) / C::NW;             // ... per wave
                 int p = 0;
                 do {
                     const int ch0 = p * C::PCH;
                     const unsigned wp = wbuf_a + wbi * C::WBUF;
-                    const int nseg = (nchunk - ch0) < C::PCH ? (nchunk - ch0) : C::PCH;      // chunks of this piece (>= 1)
+                    const int nch_p = (nchunk - ch0) < C::PCH ? (nchunk - ch0) : C::PCH;      // chunks of this piece (>= 1)
+                    const int nseg = (nch_p + SEGC - 1) / SEGC;                             // ... in segments
                     // the piece after this one: next piece of the slab (possibly short), else the first piece of the next slab / tile
                     const bool w_next = (p + 1 < npiece) || have_next;
                     const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
@@ -670,26 +677,31 @@ conv3d_f16_mfma(ConvArgs a)
                     if (p + 1 < npiece) { const int rem = wchunk - (ch0 + C::PCH); if (rem < C::PCH) w_nch = rem; }
                     else { const int nch = wchunks_of(nc8n); if (nch < C::PCH) w_nch = nch; }
                     int hnow = 0;
-                    static_for<0, C::PCH>([&](auto ccc) {
-                        constexpr int cc = decltype(ccc)::value;
-                        if (cc < nseg) {
-                            half8 xf[NPLM][MF], wf[NPLM][NF];
-                            const unsigned kos = xslab + (unsigned)ko;
-                            static_for<0, MF>([&](auto mc) {
-                                constexpr int m = decltype(mc)::value;
-                                lds_read128<0>(xf[0][m], (unsigned)xbase[m] + kos);
-                                if constexpr (SPLIT == 1) {
-                                    if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(xf[1][m], (unsigned)xbase[m] + kos);
-                                    else lds_read128<0>(xf[1][m], (unsigned)xbase[m] + kos + C::XPLANE);
+                    static_for<0, NSEGMAX>([&](auto scc) {
+                        constexpr int sc = decltype(scc)::value;
+                        if (sc < nseg) {
+                            half8 xf[SEGC][NPLM][MF], wf[SEGC][NPLM][NF];
+                            static_for<0, SEGC>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value, cc = sc * SEGC + j;
+                                if (SEGC == 1 || cc < nch_p) {
+                                    const unsigned kos = xslab + (unsigned)ko[j];
+                                    static_for<0, MF>([&](auto mc) {
+                                        constexpr int m = decltype(mc)::value;
+                                        lds_read128<0>(xf[j][0][m], (unsigned)xbase[m] + kos);
+                                        if constexpr (SPLIT == 1) {
+                                            if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(xf[j][1][m], (unsigned)xbase[m] + kos);
+                                            else lds_read128<0>(xf[j][1][m], (unsigned)xbase[m] + kos + C::XPLANE);
+                                        }
+                                    });
+                                    static_for<0, NF>([&](auto nc) {
+                                        constexpr int n = decltype(nc)::value;
+                                        lds_read128<(cc * NF + n) * C::MFRAG>(wf[j][0][n], wp);
+                                        if constexpr (SPLIT == 1) lds_read128<(cc * NF + n) * C::MFRAG + 1024>(wf[j][1][n], wp);
+                                    });
                                 }
+                                lds_read32<0>(ko_n[j], koff_a + (unsigned)(ch0 + (sc + 1) * SEGC + j) * 16);      // tap offsets of the next segment's chunks
                             });
-                            static_for<0, NF>([&](auto nc) {
-                                constexpr int n = decltype(nc)::value;
-                                lds_read128<(cc * NF + n) * C::MFRAG>(wf[0][n], wp);
-                                if constexpr (SPLIT == 1) lds_read128<(cc * NF + n) * C::MFRAG + 1024>(wf[1][n], wp);
-                            });
-                            lds_read32<0>(ko_n, koff_a + (unsigned)(ch0 + cc + 1) * 16);
-                            if constexpr (cc == 0) {
+                            if constexpr (sc == 0) {
                                 if (w_next) {
                                     const char *src = wsrc0 + w_off;
                                     char *dst = wbuf + (wbi ^ 1) * C::WBUF;
@@ -698,35 +710,37 @@ conv3d_f16_mfma(ConvArgs a)
                                 }
                                 if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
                             }
-                            // the next slab's halo tile: second chunk of the slab's first piece (first chunk if the piece has only one)
-                            if (p == 0 && have_next && !(SN_ABL & 1) && cc == (nseg >= 2 ? 1 : 0))
+                            // the next slab's halo tile: second segment of the slab's first piece (first segment if the piece has only one)
+                            if (p == 0 && have_next && !(SN_ABL & 1) && sc == (nseg >= 2 ? 1 : 0))
                                 hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
-                            if (cc == nseg - 1) {
+                            if (sc == nseg - 1) {
                                 // the next weight piece has landed; halo DMAs issued in THIS load segment may still fly unless the slab ends here
-                                if (p + 1 < npiece && cc == 1 && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
-                                else if (p + 1 < npiece && cc == 1 && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
+                                if (p + 1 < npiece && sc == 1 && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
+                                else if (p + 1 < npiece && sc == 1 && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
                                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             }
                             lgkm_wait<0>();
-                            ko = ko_n;
+                            static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; ko[j] = ko_n[j]; });
                             wg_barrier();
                             __builtin_amdgcn_sched_barrier(0);
-                            static_for<0, NF>([&](auto nc) {
-                                constexpr int n = decltype(nc)::value;
-                                if constexpr (SPLIT == 1) {
+                            static_for<0, SEGC>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value, cc = sc * SEGC + j;
+                                if (SEGC == 1 || cc < nch_p) {
 #pragma unroll
-                                    for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][n], xf[0][m], acc[m][n], 0, 0, 0);
+                                    for (int n = 0; n < NF; ++n) {
+                                        if constexpr (SPLIT == 1) {
 #pragma unroll
-                                    for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][n], xf[1][m], acc[m][n], 0, 0, 0);
+                                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][1][n], xf[j][0][m], acc[m][n], 0, 0, 0);
+#pragma unroll
+                                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][0][n], xf[j][1][m], acc[m][n], 0, 0, 0);
+                                        }
+#pragma unroll
+                                        for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][0][n], xf[j][0][m], acc[m][n], 0, 0, 0);
+                                    }
                                 }
-                                // SN_PP_EARLYBAR: the slot's closing barrier sits in FRONT of the burst's last MF MFMAs (all operands are in registers): the
-                                // partner's burst starts while they drain, which hides the barrier's own latency (~60 clocks of an idle matrix pipe per slot)
-                                if constexpr (SN_PP_EARLYBAR && n == NF - 1) { __builtin_amdgcn_sched_barrier(0); wg_barrier(); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-                                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][n], xf[0][m], acc[m][n], 0, 0, 0);
                             });
                             __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (!SN_PP_EARLYBAR) wg_barrier();
+                            wg_barrier();
                         }
                     });
                     wbi ^= 1;
@@ -744,6 +758,8 @@ conv3d_f16_mfma(ConvArgs a)
                 // buffer (group 1, loading the piece's last segment) has waited for its reads before the barrier that precedes the first
                 // load slot of the next piece, where the refill DMAs are issued.
                 static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_FMT != 0 && SN_MX_B128 && BUFH, "ping-pong loop: f16m8 kernels with 6-bit MX operands");
+                // in-burst weight prefetch: merge_conv_b -2..3 %, but merge_conv_a (store epilogue, spills) +15 % (A/B r3e-r3i) -> EPI_FINAL kernels only
+                constexpr int PPWIN = (SN_PP_WIN == 2 || (SN_PP_WIN == 1 && EPI == EPI_FINAL)) ? 1 : 0;
                 const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
                 const unsigned k2_a = koff_a + kq * 4;
                 const unsigned xslab = xbuf_a + xb * C::XBUF;       // (wave-uniform; the per-lane fragment offsets xbase[] stay the only address registers)
@@ -834,7 +850,7 @@ conv3d_f16_mfma(ConvArgs a)
                             lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
                         });
                     };
-                    // SN_PP_WIN: the NEXT segment's weight fragments are requested from inside this burst, one fragment behind every group of MF MFMAs
+                    // PPWIN: the NEXT segment's weight fragments are requested from inside this burst, one fragment behind every group of MF MFMAs
                     // (pre: 0 none | 1 the f16 fragments of chunk 2p+1 | 2 the MX step's): an LDS read costs a loading wave ~25 clocks (four waves
                     // queueing on the LDS while the partners' MFMAs own the register-file ports) but a computing wave only its issue slot, of which
                     // three in four are idle during the burst. The reads land during the wave's next load segment, whose lgkmcnt(0) covers them.
@@ -856,7 +872,7 @@ conv3d_f16_mfma(ConvArgs a)
                         });
                     };
                     using I2 = std::integral_constant<int, 2>;
-                    auto load_x = [&](auto ccc, int ko) {             // SN_PP_WIN: the activation fragments only
+                    auto load_x = [&](auto ccc, int ko) {             // PPWIN: the activation fragments only
                         constexpr int cc = decltype(ccc)::value;
                         const unsigned kos = xslab + (unsigned)ko;
                         static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<0>(xf[cc][m], (unsigned)xbase[m] + kos); });
@@ -869,8 +885,8 @@ conv3d_f16_mfma(ConvArgs a)
                     using INFA = std::integral_constant<int, NFA>;
                     using INFB = std::integral_constant<int, NFB>;
                     using INF = std::integral_constant<int, NF>;
-                    constexpr int WSPLIT = SN_PP_WIN ? SN_PP_WSPLIT : (WPW + 1) / 2;    // weight DMA instalments [0, WSPLIT) with chunk 2p, [WSPLIT, WPW) with chunk 2p+1
-                    static_assert(!(SN_PP_WIN && (SN_PP_WPRE || SN_PP_MERGE)), "SN_PP_WIN excludes SN_PP_WPRE / SN_PP_MERGE");
+                    constexpr int WSPLIT = PPWIN ? SN_PP_WSPLIT : (WPW + 1) / 2;    // weight DMA instalments [0, WSPLIT) with chunk 2p, [WSPLIT, WPW) with chunk 2p+1
+                    static_assert(!(PPWIN && (SN_PP_WPRE || SN_PP_MERGE)), "PPWIN excludes SN_PP_WPRE / SN_PP_MERGE");
                     if constexpr (SN_PP_MERGE) {
                         // ---- segment F: both f16 chunks of the piece, 2 * MF * NF MFMAs in one burst; DMA: the next weight piece; tap table of the next slab
                         PP_T(0);
@@ -911,7 +927,7 @@ conv3d_f16_mfma(ConvArgs a)
                         __builtin_amdgcn_sched_barrier(0);
                         // (chunk 2p+1's fragments are requested even when the piece has no such chunk - in-bounds reads of the zero padding, never
                         // used: a burst per case doubled the kernel's register pressure)
-                        if constexpr (SN_PP_WIN) compute_f16(I0{}, I1{}); else compute_f16(I0{}, I0{});
+                        if constexpr (PPWIN) compute_f16(I0{}, I1{}); else compute_f16(I0{}, I0{});
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
                         PP_T(4);
@@ -920,7 +936,7 @@ conv3d_f16_mfma(ConvArgs a)
                         if (has_B) {
                             PP_T(0);
                             if constexpr (SN_TIMING == 7 || SN_TIMING == 8) { if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW); PP_TA(); }
-                            if constexpr (SN_PP_WIN) load_x(I1{}, koB); else load_f16(I1{}, koB);
+                            if constexpr (PPWIN) load_x(I1{}, koB); else load_f16(I1{}, koB);
                             load_mxw(INFA{}, INFB{});
                             if constexpr (!(SN_TIMING == 7 || SN_TIMING == 8)) { if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW); }
                             halo_instalment();
@@ -929,7 +945,7 @@ conv3d_f16_mfma(ConvArgs a)
                             wg_barrier();
                             PP_T(2);
                             __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (SN_PP_WIN) compute_f16(I1{}, I2{}); else compute_f16(I1{}, I0{});
+                            if constexpr (PPWIN) compute_f16(I1{}, I2{}); else compute_f16(I1{}, I0{});
                             __builtin_amdgcn_sched_barrier(0);
                             if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
                             PP_T(4);
@@ -962,7 +978,7 @@ conv3d_f16_mfma(ConvArgs a)
                                 lds_read96i<0>(x6[m][1], (unsigned)xbase[m] + ks1);
                             }
                         });
-                        if constexpr (SN_PP_WIN && !SN_PP_MERGE) {
+                        if constexpr (PPWIN && !SN_PP_MERGE) {
                             if (!has_B) load_mxw(I0{}, INF{});              // (else: requested from inside chunk 2p+1's burst)
                         } else
                         if (!(SN_PP_WPRE && (SN_PP_MERGE || has_B))) {

@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
     // RP_LIST voxels, i.e. every realistic surface) the passes below touch only the selected voxels with all lanes busy; without it
     // a wave runs the fp64 projection whenever ANY of its 64 lanes holds a selected voxel - 32 times per lane at 1 % selected as at 10 %.
     __shared__ unsigned sh_list[RP_LIST], sh_q[RP_LIST];
+    // 2 x 32 KiB + sh_i: more than the 64 KiB of LDS a workgroup gets on CDNA1-3 - this library is built for gfx950 only (Makefile: 160 KiB per
+    // CU, and the 1024-thread workgroup owns its CU anyway). Halve RP_LIST before retargeting.
+    static_assert(sizeof(sh_list) + sizeof(sh_q) + 64 <= 160 * 1024, "ray_pool_kernel's selected-voxel list exceeds gfx950's LDS");
     if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0x7fffffff; sh_i[2] = 0; }
     __syncthreads();
     for (int i = tid; i < V3; i += RP_NT) {

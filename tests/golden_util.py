@@ -22,8 +22,17 @@ def cvc_cases():
 
 
 def case_images(case):
+    if "imgs" in case:                    # real-pixel cases (real_cases.npz) carry their decoded windows
+        return [np.ascontiguousarray(im) for im in case["imgs"]]
     H, W = case["HW"]
     return [synth_image(sd, H, W) for sd in case["seeds"]]
+
+
+def real_cases():
+    """CVC golden cases on windows of real DTU scan9 / Middlebury dino views (oracle/gen_golden_real.py)."""
+    z = np.load(os.path.join(GOLDEN, "real_cases.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    return {n: {k.split("/")[1]: z[k] for k in z.files if k.startswith(n + "/")} for n in names}
 
 
 def cameras():

@@ -31,6 +31,28 @@ def test_cvc_warp_bit_exact_vs_reference_golden(sn, name):
     assert np.array_equal(out, c["out_u8"].astype(np.float32))
 
 
+@pytest.mark.parametrize("name", ["dtu_real", "mid_real"])
+def test_real_dataset_pixels_cvc_bit_exact_and_cnn_parity(sn, name):
+    """Real DTU scan9 / Middlebury dino pixels (tests/golden/real_cases.npz, written by executing the reference's CVC.py on decoded windows
+    of the dataset images): the HIP warp is bit-exact against the reference's output, and the CNN - fed these piecewise-smooth, heavy-tailed
+    colour cubes instead of noise - stays within the default mode's tolerance of the fp64 oracle, fused entry and three-call protocol alike."""
+    import synth
+    from oracle import net_oracle
+    c = golden_util.real_cases()[name]
+    s, n_vp = int(c["s"]), 1
+    values = list(synth.calibrated_params(1))
+    with sn.Context(cube_D=s, max_samples=2) as ctx:
+        ctx.set_cameras(c["P"]); ctx.set_images(golden_util.case_images(c)); ctx.load_param_values(values)
+        raw = ctx.cvc(c["pairs"], c["xyz"], c["resol"])
+        assert np.array_equal(raw, c["out_u8"].astype(np.float32))
+        fused, unfused, cvc = ctx.cvc_forward(c["pairs"], c["xyz"], c["resol"], None, return_cvc=True)
+    assert np.array_equal(cvc[:1], c["pre_f32_cube0"])
+    f64, u64 = net_oracle.forward_torch(cvc, values, w=None, n_vp=n_vp)
+    err = float(np.abs(unfused - u64).max())
+    print("%s: L_inf vs fp64 oracle on real pixels %.3e (probabilities %.3f .. %.3f)" % (name, err, u64.min(), u64.max()))
+    assert err < TOL_X3 and np.array_equal(fused, unfused)
+
+
 def test_cvc_preprocess_golden_and_chunking(sn):
     c = CASES["dtu_s8_vp1"]
     with _ctx_for_case(sn, c, max_samples=2) as ctx:      # 3 samples through a 2-sample workspace -> chunked

@@ -26,6 +26,23 @@ def test_numpy_restatement_matches_reference_golden(name):
     assert np.array_equal(out, c["out_u8"].astype(np.float32))
 
 
+@pytest.mark.parametrize("name", ["dtu_real", "mid_real"])
+def test_oracle_matches_reference_on_real_dataset_pixels(name):
+    """Windows of two DTU scan9 JPEGs / two Middlebury dino PNGs (decoded in the build container, stored as arrays) with the principal
+    point of their P matrices shifted to the window origin; expected outputs from the reference's own CVC.py (oracle/gen_golden_real.py).
+    One cube inside both windows, one crossing the window border."""
+    c = golden_util.real_cases()[name]
+    imgs = golden_util.case_images(c)
+    assert imgs[0].shape == (128, 160, 3) and imgs[0].dtype == np.uint8 and imgs[0].std() > 10       # real pixels, not a constant
+    for fn in (cvc_oracle.gen_coloredCubes, cvc_oracle.gen_coloredCubes_numpy):
+        out = fn(c["pairs"], c["xyz"], c["resol"], c["P"], imgs, int(c["s"]))
+        assert np.array_equal(out, c["out_u8"].astype(np.float32))
+    pre = cvc_oracle.gen_coloredCubes(c["pairs"][:1], c["xyz"][:1], c["resol"][:1], c["P"], imgs, int(c["s"]), mean6=golden_util.MEAN6)
+    assert np.array_equal(pre, c["pre_f32_cube0"])
+    frac = (c["out_u8"][1].reshape(2, 3, -1).max(axis=1) > 0).mean()
+    assert 0.2 < frac < 0.9                                   # the second cube really leaves the window
+
+
 def test_preprocess_golden():
     c = CASES["dtu_s8_vp1"]
     out = cvc_oracle.gen_coloredCubes(c["pairs"], c["xyz"], c["resol"], c["P"], golden_util.case_images(c), 8, mean6=golden_util.MEAN6)

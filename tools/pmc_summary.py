@@ -58,7 +58,9 @@ def main():
         if "SQ_LDS_BANK_CONFLICT" in p and p.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_conflict_frac"] = round(p["SQ_LDS_BANK_CONFLICT"] / p["SQ_LDS_IDX_ACTIVE"], 4)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in p and "GRBM_GUI_ACTIVE" in out["kernels"][k].get("pmc_per_launch", {}):
-            d["mfma_util"] = round(p["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * p["GRBM_GUI_ACTIVE"] / 8), 4)
+            d["mfma_util"] = round(p["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * p["GRBM_GUI_ACTIVE"] / 8), 4)      # 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        if "SQ_LDS_IDX_ACTIVE" in p and "GRBM_GUI_ACTIVE" in p:
+            d["lds_busy"] = round(p["SQ_LDS_IDX_ACTIVE"] / (256 * p["GRBM_GUI_ACTIVE"] / 8), 4)                  # 256 CUs, one LDS each
     json.dump(out, open(a.out, "w"), indent=1, sort_keys=True)
     print("wrote", a.out, "with", len(out["kernels"]), "kernels")
 
