@@ -112,6 +112,9 @@
 #ifndef SN_PPX
 #define SN_PPX 1          // 1: ping-pong K loop for the f16 / f16x3 3x3 kernels with at least two K-chunks per weight piece
 #endif
+#ifndef SN_PPX_MINNF
+#define SN_PPX_MINNF 1    // narrowest kernel (cout fragments per workgroup) that takes the ping-pong loop
+#endif
 #ifndef SN_PPX_SEGC
 #define SN_PPX_SEGC 1     // 2: two K-chunks per ping-pong segment where a chunk is a short burst (MF * NF <= 8: conv1_x)
 #endif
@@ -417,7 +420,7 @@ conv3d_f16_mfma(ConvArgs a)
     // slab fits the offset field. The one-plane f16 mode of the 2-D nets (4-group slabs: up to 400 MB) keeps the generic path.
     constexpr bool BUFH = (K2D == 0) || (SPLIT != 0);
     constexpr bool PPM = SN_PP && SPLIT == 2 && K2D == 0 && NW_ == 8 && KS == 3 && SN_MX_FMT != 0;   // ping-pong K loop, f16m8 kernels (slab loop)
-    constexpr bool PPX = SN_PPX && SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && BUFH;          // ... f16 / f16x3 kernels
+    constexpr bool PPX = SN_PPX && SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && BUFH && NF >= SN_PPX_MINNF;          // ... f16 / f16x3 kernels
     constexpr bool PP = PPM || PPX;
     constexpr unsigned FB_YLO = K2D ? (1u << 31) : HB_YLO, FB_YHI = K2D ? (1u << 30) : HB_YHI, FB_ZLO = K2D ? (1u << 29) : HB_ZLO,
                        FB_ZHI = K2D ? (1u << 28) : HB_ZHI, FB_NEVER = K2D ? 0x0FFFFFF0u : HB_ALWAYS, FB_OFFMASK = K2D ? 0x0FFFFFFFu : HB_OFFMASK;
@@ -1428,6 +1431,13 @@ conv3d_f16_mfma(ConvArgs a)
             // R2: the two rows of a fragment lie 2 apart (conflict-free LDS reads, SN_ROWGAP_2D): the row partner of a pixel is the SAME lane of
             // fragment m ^ 1 (rows r and r + 1), every lane row of fragment m = 0, 2 writes one pooled row
             constexpr bool R2 = (K2D == 1 && (SN_ROWGAP_2D == 2 || SN_ROWGAP_2D == 4) && C::VS == 32);   // (64-byte pixels, f16 mode: adjacent rows are already 640 bytes apart)
+            f32x4 scv[NF], shv[NF];           // all fragments' constants before the first store (see EPI_STORE)
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
+                scv[n] = *reinterpret_cast<const f32x4 *>(a.scale + nl);
+                shv[n] = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+            }
 #pragma unroll
             for (int m = 0; m < MF; m += (R2 ? 2 : 1)) {
                 int hx_, hy_, hz_;
@@ -1438,8 +1448,7 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                    const f32x4 sc = scv[n], sh = shv[n];
                     half4 h, l;
                     float lo32[4];
 #pragma unroll
@@ -1602,7 +1611,9 @@ conv3d_f16_mfma(ConvArgs a)
                 frag_xyz(mm, hx, hy, hz);
                 const int gx = x0 + hx, gy = y0 + hy, gz = z0 + hz;
                 const bool writer = !(v & 1) && (SN_PMAP_GAP4 || !(v & 8)) && gx < DX && gy < D && gz < D;     // D even: the whole cell is inside
-                const size_t vlin = ((size_t)(gx >> 1) * Do + (gy >> 1)) * Do + (gz >> 1);
+                // per-lane part of the store address as ONE 32-bit byte offset (pooled voxel, the lane's half of its 8-channel group, + one group
+                // plane for kq >= 2), the rest wave-uniform: see EPI_STORE (a spilled 64-bit address reloaded inside the store loop = vmcnt(0) per store)
+                const unsigned pvoff = ((unsigned)(((gx >> 1) * Do + (gy >> 1)) * Do + (gz >> 1)) + (unsigned)(kq >> 1) * (unsigned)VOLo) * 16u + (unsigned)(kq & 1) * 8u;
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
                     half4 h, l;
@@ -1624,7 +1635,8 @@ conv3d_f16_mfma(ConvArgs a)
                     }
                     const int ch = n * 16 + kq * 4;
                     if (writer && ch < a.out_cp) {
-                        _Float16 *o = a.pool_out + (size_t)b * VOLo * a.pool_cs + ((size_t)(ch >> 3) * VOLo + vlin) * 8 + (ch & 7);
+                        char *const plane = reinterpret_cast<char *>(a.pool_out) + 2 * ((size_t)b * VOLo * a.pool_cs + (size_t)(2 * n) * VOLo * 8);     // wave-uniform
+                        _Float16 *o = reinterpret_cast<_Float16 *>(plane + pvoff);
                         *reinterpret_cast<half4 *>(o) = h;
                         if constexpr (SPLIT == 1) *reinterpret_cast<half4 *>(o + a.pool_lo_off) = l;
                         if constexpr (SPLIT == 2) {
@@ -1649,28 +1661,37 @@ conv3d_f16_mfma(ConvArgs a)
             static_assert(MF % 2 == 0, "paired store epilogue");
             const bool odd = kq & 1;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            // The folded BN constants of all NF fragments are fetched BEFORE the first store (the K loop's operand registers are free by now): a
+            // global load between stores makes hipcc wait vmcnt(0) in front of its use, i.e. for the stores issued before it - one HBM round trip
+            // per (fragment pair, cout fragment): 8-10 per tile, a third of conv1_x's tile time (round 3; wide layers keep theirs in LDS, CST_LDS)
+            f32x4 scv[C::CST_LDS ? 1 : NF], shv[C::CST_LDS ? 1 : NF];
+            if constexpr (!C::CST_LDS) {
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
+                    const int nlc = nl < a.out_cp ? nl : 0;
+                    scv[n] = *reinterpret_cast<const f32x4 *>(a.scale + nlc);
+                    shv[n] = *reinterpret_cast<const f32x4 *>(a.shift + nlc);
+                }
+            }
 #pragma unroll
             for (int mp = 0; mp < MF; mp += 2) {
-                bool valid[2];
-                size_t vlin[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int m = mp + e;
-                    int hx_, hy_, hz_;
-                frag_xyz(m, hx_, hy_, hz_);
+                // This lane stores fragment mp (kq even) or mp + 1 (kq odd). Its store address = a wave-uniform plane base (sample, channel group of
+                // fragment n: scalar registers) + ONE 32-bit per-lane byte offset (voxel slot, + one group plane for the lane pairs kq >= 2 that hold
+                // channels 8..15 of the fragment): 64-bit per-lane addresses kept across the n loop were spilled, and a scratch reload inside a store
+                // loop makes hipcc wait vmcnt(0), i.e. for every store issued before it - one HBM round trip per iteration (merge_conv_a: 34 spilled
+                // registers, ~19 us of epilogue per tile, round 3)
+                int hx_, hy_, hz_;
+                frag_xyz(mp + (odd ? 1 : 0), hx_, hy_, hz_);
                 const int gx = x0 + hx_, gy = y0 + hy_, gz = z0 + hz_;
-                    valid[e] = gx < DX && gy < D && gz < D;
-                    vlin[e] = ((size_t)gx * D + gy) * D + gz;
-                }
-                const bool my_valid = odd ? valid[1] : valid[0];
-                const size_t my_vlin = odd ? vlin[1] : vlin[0];
+                const bool my_valid = gx < DX && gy < D && gz < D;
+                const unsigned my_voff = ((unsigned)((gx * D + gy) * D + gz) + (unsigned)(kq >> 1) * (unsigned)VOL) * 16u;
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
                     const bool ch_ok = nl < a.out_cp;                    // out_cp is a multiple of 8: both lanes of a pair agree
-                    const int nlc = ch_ok ? nl : 0;
-                    const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.scale + nlc);
-                    const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + NF * 16 + n * 16 + kq * 4) : *reinterpret_cast<const f32x4 *>(a.shift + nlc);
+                    const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + n * 16 + kq * 4) : scv[C::CST_LDS ? 0 : n];
+                    const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + NF * 16 + n * 16 + kq * 4) : shv[C::CST_LDS ? 0 : n];
                     unsigned hw[2][2], lw[2][2];                          // [fragment of the pair][dword]: hi plane, second plane
                     _Float16 hq[2][4];
                     float loq[2][4];
@@ -1710,8 +1731,9 @@ conv3d_f16_mfma(ConvArgs a)
                     // r[0] = {own (even kq) | lower partner's fragment-(m+1) half (odd kq)}, r[1] = {upper partner's fragment-m half | own}
                     const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
                     const auto h1 = __builtin_amdgcn_permlane16_swap(hw[0][1], hw[1][1], false, false);
-                    const int ch = a.out_coff + (nl & ~7);               // first channel of this lane pair's 8-channel group
-                    _Float16 *o = a.out + (size_t)b * VOL * a.out_cs + ((size_t)(ch >> 3) * VOL + my_vlin) * 8;
+                    const int g0 = (a.out_coff + (blockIdx.y * NF + n) * 16) >> 3;      // first 8-channel group of fragment n (out_coff is a multiple of 8)
+                    char *const plane = reinterpret_cast<char *>(a.out) + 2 * ((size_t)b * VOL * a.out_cs + (size_t)g0 * VOL * 8);     // wave-uniform
+                    _Float16 *o = reinterpret_cast<_Float16 *>(plane + my_voff);
                     const bool st = my_valid && ch_ok;
                     if (st) *reinterpret_cast<u32x4 *>(o) = u32x4{h0[0], h1[0], h0[1], h1[1]};
                     if constexpr (OSPLIT == 1) {

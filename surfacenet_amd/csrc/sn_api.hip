@@ -327,7 +327,10 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
               ma = A(c->ma, v1, 104), none = Act{nullptr, 0};
     int rc;
 #define RUN(x) do { if ((rc = (x)) != SN_OK) return rc; } while (0)
-#define CONV1 3, 1, 4, 2, EPI_STORE, SP, 1, (SP == 2 ? 2 : 7), 8, 0
+#ifndef SN_C1_MF
+#define SN_C1_MF 8        // voxel fragments per wave of conv1_1 / conv1_2: 8 = 16x8x8 tiles (half the weight staging and weight-fragment reads per MFMA: -6..7 %, A/B r3l), 4-chunk weight pieces - the LDS holds no more
+#endif
+#define CONV1 3, 1, SN_C1_MF, 2, EPI_STORE, SP, 1, (SP == 2 ? 2 : (SN_C1_MF == 8 ? 4 : 7)), 8, 0
 #define SIDE  1, 1, 4, 1, EPI_STORE, SP, 5, 2, 4, 0
 // conv2_x / conv3_x: 16-channel slabs with one-chunk weight pieces; the ping-pong loop (SN_PPX) needs >= 2 chunks per piece, which fits the
 // LDS only with 8-channel slabs (4-chunk pieces: a 7-chunk slab = pieces of 4 + 3)

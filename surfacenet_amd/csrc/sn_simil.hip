@@ -16,7 +16,10 @@ static constexpr int kSimChunk = 2040;
 // channel groups per slab / K-chunks per weight piece: f16x3 (two activation planes) 2 / 2 (3 measured equal); f16 (one plane)
 // 4 / 3, i.e. 36 groups = exactly 9 chunks per slab: +18 % in that mode
 #define SIMCS8 (SP == 0 ? 4 : 2)
-#define SIMPCH (SP == 0 ? 3 : 2)
+#ifndef SN_SIMPCH
+#define SN_SIMPCH 2
+#endif
+#define SIMPCH (SP == 0 ? 3 : SN_SIMPCH)
 static int simil_cs8(int mode) { return mode == 0 ? 4 : 2; }
 #define SCONV 3, 1, 4, kSimNF, EPI_STORE, SP, SIMCS8, SIMPCH, 8, 0, 1
 // the 4x4 maps of conv5_x: one MFMA voxel fragment = one image (K2D = 2), 16 images x 128 output channels per workgroup
