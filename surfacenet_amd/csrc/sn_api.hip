@@ -84,8 +84,11 @@ static float mx6_max(int fmt) { return fmt == 2 ? 7.5f : 28.f; }
 //   * a ReLU layer stores y * 2^out_exp[o] (ReLU commutes with positive scaling): scale and shift absorb 2^out_exp[o].
 // conv(2^a x) * 2^b == 2^(a+b) conv(x) exactly in binary floating point as long as nothing over/underflows, so the network
 // function is unchanged; in_exp / out_exp may be null (all zero).
-int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, const float *gamma, const float *mean,
-              const float *inv_std, int nf, int nsplit, int cs8max, int split, const int *in_exp, const int *out_exp)
+// Host half: everything up to the three arrays that go to the device (h: packed fragments, sc / sh: folded BN). No device call, so the
+// address-sanitizer build exercises its index arithmetic on the CPU (tests/test_asan.py through sn_debug_pack_host).
+static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, const float *gamma, const float *mean,
+                          const float *inv_std, int nf, int nsplit, int cs8max, int split, const int *in_exp, const int *out_exp,
+                          std::vector<_Float16> &h, std::vector<float> &sc, std::vector<float> &sh)
 {
     L.nf = nf; L.nsplit = nsplit; L.cs8max = cs8max; L.split = split;
     L.cin_p = round_up(L.cin, 8);
@@ -117,7 +120,7 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, co
         const int ci = c8abs * 8 + j;
         return (o < L.cout && ci < L.cin) ? W[((size_t)o * L.cin + ci) * ntap + tap] : 0.f;
     };
-    std::vector<_Float16> h;
+    h.clear();
     if (split != 2) {
         long long chunks = 0;
         for (unsigned char c8n : L.slab_c8) chunks += (ntap * c8n + 3) / 4;
@@ -234,7 +237,8 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, co
             }
         }
     }
-    std::vector<float> sc((size_t)nsplit * nf * 16 + 16, 0.f), sh((size_t)nsplit * nf * 16 + 16, 0.f);
+    sc.assign((size_t)nsplit * nf * 16 + 16, 0.f);
+    sh.assign((size_t)nsplit * nf * 16 + 16, 0.f);
     for (int o = 0; o < L.cout; ++o) {
         const float s = gamma[o] * inv_std[o];   // Lasagne BatchNormLayer, deterministic=True
         const int oe = out_exp ? out_exp[o] : 0;
@@ -244,14 +248,23 @@ int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, co
             return fail(SN_ERR_ARG, "%s: folded BatchNorm scale / shift of output channel %d leaves the fp32 range (gamma %g, inv_std %g, "
                                     "row exponent %d, output exponent %d)", L.name.c_str(), o, gamma[o], inv_std[o], row_exp[o], oe);
     }
+    L.macs_per_voxel = (double)L.cin * L.cout * ntap;
+    return SN_OK;
+}
+
+int pack_conv(sn_ctx *c, PackedConv &L, const float *W_in, const float *beta, const float *gamma, const float *mean,
+              const float *inv_std, int nf, int nsplit, int cs8max, int split, const int *in_exp, const int *out_exp)
+{
+    std::vector<_Float16> h;
+    std::vector<float> sc, sh;
     int rc;
+    if ((rc = pack_conv_host(L, W_in, beta, gamma, mean, inv_std, nf, nsplit, cs8max, split, in_exp, out_exp, h, sc, sh)) != SN_OK) return rc;
     if ((rc = dev_alloc(c, &L.wpack, h.size() + 8192)) != SN_OK) return rc;
     if ((rc = dev_alloc(c, &L.scale, sc.size())) != SN_OK) return rc;
     if ((rc = dev_alloc(c, &L.shift, sh.size())) != SN_OK) return rc;
     HIPCHK(hipMemcpy(L.wpack, h.data(), h.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(L.scale, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(L.shift, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
-    L.macs_per_voxel = (double)L.cin * L.cout * ntap;
     return SN_OK;
 }
 
@@ -1162,6 +1175,26 @@ SN_API int sn_debug_tensor(sn_ctx *c, const char *name, void *host, size_t bytes
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost));
+    return SN_OK;
+}
+
+// Test hook: the HOST half of pack_conv for one layer description (row-major (cout, cin, taps) weights, taps = ks^3 or ks^2 with k2d) - lets
+// the address-sanitizer twin (make asan, tests/test_asan.py) run the fragment packer's index arithmetic for every layer shape and
+// precision mode without a GPU. out[0..2] = sizes of the three packed arrays, out[3] = a byte checksum of the packed fragments.
+SN_API int sn_debug_pack_host(int cin, int cout, int ks, int dil, int k2d, int nf, int nsplit, int cs8max, int split, const float *W, const float *beta,
+                              const float *gamma, const float *mean, const float *inv_std, unsigned long long *out)
+{
+    if (!W || !beta || !gamma || !mean || !inv_std || !out) return fail(SN_ERR_ARG, "null argument");
+    PackedConv L;
+    L.name = "debug"; L.cin = cin; L.cout = cout; L.ks = ks; L.dil = dil; L.k2d = k2d;
+    std::vector<_Float16> h;
+    std::vector<float> sc, sh;
+    const int rc = pack_conv_host(L, W, beta, gamma, mean, inv_std, nf, nsplit, cs8max, split, nullptr, nullptr, h, sc, sh);
+    if (rc != SN_OK) return rc;
+    unsigned long long sum = 0;
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(h.data());
+    for (size_t i = 0; i < h.size() * sizeof(_Float16); ++i) sum = sum * 1099511628211ull + b[i];
+    out[0] = h.size(); out[1] = sc.size(); out[2] = sh.size(); out[3] = sum;
     return SN_OK;
 }
 

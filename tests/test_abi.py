@@ -36,7 +36,7 @@ def test_header_binding_and_library_agree(built):
     dbg = os.path.join(os.path.dirname(built.LIB_PATH), "libsurfacenet_hip_dbg.so")       # the test-only twin: the same ABI + the hooks
     out = subprocess.check_output(["nm", "-D", "--defined-only", dbg]).decode()
     exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
-    assert set(hdr) <= set(exported) and set(exported) - set(hdr) == {"sn_debug_tensor", "sn_debug_mx6_encode", "sn_debug_timing", "sn_debug_trace"}
+    assert set(hdr) <= set(exported) and set(exported) - set(hdr) == {"sn_debug_tensor", "sn_debug_mx6_encode", "sn_debug_timing", "sn_debug_trace", "sn_debug_pack_host"}
 
 
 def test_version_and_no_gpu_fails_loudly(built):
