@@ -178,6 +178,69 @@ __global__ void __launch_bounds__(256) upsample3_cat_kernel(const _Float16 *s2, 
     sn_store8<OSPLIT>(o, out_lo_off, acc, out_e8);   // OSPLIT: storage format the consumer (merge_conv_a) computes in
 }
 
+// The same, LDS-tiled (round 3): one workgroup = an 8 x 8 x Do block of output voxels of ONE destination group. The source voxels the
+// block's stencils touch ((8/F+1)^2 x (Do/F+1): 425 for the x2 map, 81 for the x4 maps) are fetched ONCE into LDS as fp32 groups and every
+// output voxel sums its <= 8 corners from there - in the per-voxel kernel above every thread fetches its own corners from L2 (~10 16-byte
+// loads per thread, 13 TB/s of L2 traffic for 0.8 GB of output). Same corner order and fp32 arithmetic: bit-identical results.
+// Requires Do % 8 == 0 (launch_up3 falls back to the per-voxel kernel otherwise).
+template <int SPLIT, int OSPLIT = SPLIT>
+__global__ void __launch_bounds__(256) upsample3_cat_tiled_kernel(const _Float16 *s2, const _Float16 *s3, const _Float16 *s4, _Float16 *cat,
+                                                                  int Do, int cat_cs, long long lo2, long long lo3, long long lo4,
+                                                                  long long out_lo_off, int out_e8)
+{
+    constexpr int TB = 8, SMAX = (TB / 2 + 1) * (TB / 2 + 1);            // source (x, y) footprint of a tile, x2 case: 5 x 5
+    __shared__ float src[SMAX * 33 * 8];                                 // [sx][sy][sz <= Do/2 + 1 <= 33][8]  (Do <= 64)
+    const int tiles = Do / TB;
+    int t = blockIdx.x;
+    const int ty = t % tiles; t /= tiles;
+    const int tx = t % tiles; t /= tiles;
+    const int g = t % 6;
+    const long long b = t / 6;
+    const int srcsel = g >> 1, c8 = g & 1;                               // 0: s2 (x2), 1: s3 (x4), 2: s4 (x4)
+    const int F = srcsel == 0 ? 2 : 4;
+    const _Float16 *in = srcsel == 0 ? s2 : (srcsel == 1 ? s3 : s4);
+    const long long in_lo = srcsel == 0 ? lo2 : (srcsel == 1 ? lo3 : lo4);
+    const int Di = Do / F, x0 = tx * TB, y0 = ty * TB, mx0 = x0 / F, my0 = y0 / F;
+    const int nsx = TB / F + 1, nsz = Di + 1;                            // source extent per axis (one past the end: weight 0 there, slot zero-filled)
+    for (int i = threadIdx.x; i < nsx * nsx * nsz; i += 256) {
+        const int sz = i % nsz, sy = (i / nsz) % nsx, sx = i / (nsz * nsx);
+        float q[8];
+        const int gx = mx0 + sx, gy = my0 + sy;
+        if (gx < Di && gy < Di && sz < Di) sn_load8<SPLIT>(in + (((((b * 2 + c8) * Di + gx) * Di + gy) * Di + sz) * 8LL), in_lo, q);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = 0.f;
+        }
+        float *d = src + ((sx * nsx + sy) * 33 + sz) * 8;
+        *reinterpret_cast<float4 *>(d) = float4{q[0], q[1], q[2], q[3]};
+        *reinterpret_cast<float4 *>(d + 4) = float4{q[4], q[5], q[6], q[7]};
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TB * TB * Do; idx += 256) {        // consecutive threads = consecutive z: coalesced 16-byte stores
+        const int z = idx % Do, y = y0 + (idx / Do) % TB, x = x0 + idx / (Do * TB);
+        int mx, my, mz;
+        float ax, bx, ay, by, az, bz;
+        if (srcsel == 0) { up_axis<2>(x, Di, mx, ax, bx); up_axis<2>(y, Di, my, ay, by); up_axis<2>(z, Di, mz, az, bz); }
+        else             { up_axis<4>(x, Di, mx, ax, bx); up_axis<4>(y, Di, my, ay, by); up_axis<4>(z, Di, mz, az, bz); }
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int dx = o >> 2, dy = (o >> 1) & 1, dz = o & 1;
+            const float w = (dx ? bx : ax) * (dy ? by : ay) * (dz ? bz : az);
+            if (w != 0.f) {
+                const float *q = src + (((mx - mx0 + dx) * nsx + (my - my0 + dy)) * 33 + mz + dz) * 8;
+                const float4 q0 = *reinterpret_cast<const float4 *>(q), q1 = *reinterpret_cast<const float4 *>(q + 4);
+                acc[0] += w * q0.x; acc[1] += w * q0.y; acc[2] += w * q0.z; acc[3] += w * q0.w;
+                acc[4] += w * q1.x; acc[5] += w * q1.y; acc[6] += w * q1.z; acc[7] += w * q1.w;
+            }
+        }
+        _Float16 *o = cat + ((((b * (cat_cs >> 3) + 2 + g) * Do + x) * Do + y) * Do + z) * 8LL;
+        sn_store8<OSPLIT>(o, out_lo_off, acc, out_e8);
+    }
+}
+
 // unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.
 static __global__ void __launch_bounds__(256) fuse_kernel(const float *unfused, const float *w, float *fused, int n_vp, int s3, long long total)
 {

@@ -320,6 +320,11 @@ static int launch_up3(sn_ctx *c, Act s2, Act s3, Act s4, Act cat, int B, int Do,
 {
     const long long total = (long long)B * Do * Do * Do * 6;
     ProfScope ps(c, "side_op234_deconv", 0, (double)B * Do * Do * Do * 48 * 2.0 * (SPLIT ? 2 : 1));
+    static const bool per_voxel = getenv("SN_UPSAMPLE_PER_VOXEL") != nullptr;       // A/B: the round-1 kernel (one thread per output voxel, corners from L2)
+    if (Do % 8 == 0 && Do <= 64 && !per_voxel)
+        hipLaunchKernelGGL((upsample3_cat_tiled_kernel<SPLIT, OSPLIT>), dim3((unsigned)(B * 6 * (Do / 8) * (Do / 8))), dim3(256), 0, c->stream, s2.p, s3.p, s4.p,
+                           cat.p, Do, cat_cs, s2.lo, s3.lo, s4.lo, cat.lo, c->mx_cat_e8);
+    else
     hipLaunchKernelGGL((upsample3_cat_kernel<SPLIT, OSPLIT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, s2.p, s3.p, s4.p,
                        cat.p, Do, cat_cs, total, s2.lo, s3.lo, s4.lo, cat.lo, c->mx_cat_e8);
     HIPCHK(hipGetLastError());
