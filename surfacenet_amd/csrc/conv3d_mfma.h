@@ -194,6 +194,7 @@ enum { EPI_STORE = 0, EPI_FINAL = 1, EPI_POOL2D = 2, EPI_SIDEPOOL = 3 };   // PO
 // SIDEPOOL (3-D nets): the layer's own output is never stored - its two consumers, the 1x1x1 side convolution (+BN+sigmoid, one more
 // MFMA chain on the in-register outputs) and the 2x2x2 max-pool, run in the epilogue and store THEIR outputs (nets/SurfaceNet.py:37-38,46-47)
 
+template <int V> struct IntC { static constexpr int value = V; };
 __device__ __forceinline__ float sn_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // Numeric status of one epilogue value: t = the pre-activation (folded BN of the accumulator), y = what is stored. ReLU maps a NaN or -inf
 // pre-activation to 0, so the test has to look at t: not finite (an accumulator that overflowed or met inf - inf upstream), or y beyond fp16.
@@ -1659,7 +1660,17 @@ conv3d_f16_mfma(ConvArgs a)
             // swap_probe.hip): afterwards the even-kq lanes hold the whole group of fragment m, the odd-kq lanes that of m+1,
             // and every lane issues ONE 16-byte store per plane instead of two 8-byte ones (the tail is store-issue bound).
             static_assert(MF % 2 == 0, "paired store epilogue");
+            // The activation is a launch argument; the body is instantiated once per activation and the choice made ONCE per tile: with
+            // `a.act == 0 ? relu : sigmoid` inside the value loop hipcc kept a (uniform) branch pair per VALUE - 2 x 112 taken branches per
+            // wave and tile in merge_conv_a, with the sigmoid's division chain laid out in the fall-through path (round 3)
+            auto store_tile = [&](auto act_c) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_c)::value;
             const bool odd = kq & 1;
+            // (opaque per-tile lane offset into the constant table: otherwise hipcc hoists the 2 * NF LDS addresses out of the tile loop, keeps
+            // them live across the K loop and spills them - a scratch reload + vmcnt(0), i.e. a wait for the stores in flight, per fragment pair)
+            int cst_lane = kq * 4;
+            asm volatile("" : "+v"(cst_lane));
+            const float *const cstl = cst + cst_lane;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             // The folded BN constants of all NF fragments are fetched BEFORE the first store (the K loop's operand registers are free by now): a
             // global load between stores makes hipcc wait vmcnt(0) in front of its use, i.e. for the stores issued before it - one HBM round trip
@@ -1690,8 +1701,8 @@ conv3d_f16_mfma(ConvArgs a)
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
                     const bool ch_ok = nl < a.out_cp;                    // out_cp is a multiple of 8: both lanes of a pair agree
-                    const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + n * 16 + kq * 4) : scv[C::CST_LDS ? 0 : n];
-                    const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cst + NF * 16 + n * 16 + kq * 4) : shv[C::CST_LDS ? 0 : n];
+                    const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cstl + n * 16) : scv[C::CST_LDS ? 0 : n];
+                    const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cstl + NF * 16 + n * 16) : shv[C::CST_LDS ? 0 : n];
                     unsigned hw[2][2], lw[2][2];                          // [fragment of the pair][dword]: hi plane, second plane
                     _Float16 hq[2][4];
                     float loq[2][4];
@@ -1702,7 +1713,7 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float pre = acc[mp + e][n][r] * sc[r] + sh[r];
-                            float y = a.act == 0 ? fmaxf(pre, 0.f) : sn_sigmoid(pre);
+                            float y = ACT == 0 ? fmaxf(pre, 0.f) : sn_sigmoid(pre);
                             bad |= sn_bad_value(pre, y);     // (the pre-activation: ReLU would turn a NaN / -inf accumulator into a clean 0)
                             if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
@@ -1752,6 +1763,11 @@ conv3d_f16_mfma(ConvArgs a)
                     }
                 }
             }
+            };
+            // (sigmoid store layers exist only as 1x1x1 side convolutions; the 3x3x3 kernels carry the ReLU body alone - the launcher refuses
+            // anything else - because a second, sigmoid-sized body raised the register pressure of the ReLU one: spill reloads inside its store loop)
+            if constexpr (KS == 1) { if (a.act == 0) store_tile(IntC<0>{}); else store_tile(IntC<1>{}); }
+            else store_tile(IntC<0>{});
         } else {
             // fused merge_conv3: ReLU(BN(acc)) . w3 over the NF*16 channels; the per-channel constants are re-read
             // per voxel fragment (L1/L2 hits) instead of being kept live, which keeps the kernel within 256 registers

@@ -246,6 +246,8 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
             return fail(SN_ERR_ARG, "%s: %d images of %dx%d exceed the 256 MiB this kernel's halo addressing covers per channel slab", L.name.c_str(), DX, D, D);
     }
     a.act = L.act;
+    if (EPI == EPI_STORE && KS != 1 && L.act != 0)       // conv3d_mfma.h: only the 1x1x1 store kernels carry the sigmoid epilogue
+        return fail(SN_ERR_STATE, "%s: a sigmoid activation is only built for the 1x1x1 store kernels", L.name.c_str());
     {
         // static premultipliers of the 6-bit code planes (mx_format.h): the concat buffer holds sigmoid outputs, everything else ReLU(BN(.))
         auto e8_of = [&](const _Float16 *t) { return t && t == c->cat ? c->mx_cat_e8 : (t && t == c->x0 ? kMxX0E8 : c->mx_act_e8); };
