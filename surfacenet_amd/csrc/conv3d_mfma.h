@@ -199,6 +199,21 @@ __device__ __forceinline__ float sn_sigmoid(float x) { return 1.0f / (1.0f + __e
 // Numeric status of one epilogue value: t = the pre-activation (folded BN of the accumulator), y = what is stored. ReLU maps a NaN or -inf
 // pre-activation to 0, so the test has to look at t: not finite (an accumulator that overflowed or met inf - inf upstream), or y beyond fp16.
 __device__ __forceinline__ bool sn_bad_value(float t, float y) { return !(fabsf(t) <= 3.0e38f) || !(y <= 65504.f); }
+// The store epilogues track the same two conditions with one packed VALU op per PAIR of values instead of two compares and a scalar OR per
+// value: c = fma(x, 0, c) stays (+-)0 while every x is finite and turns into a sticky NaN at the first +-inf / NaN (inf * 0 = NaN); run over the
+// ACCUMULATORS it finds a non-finite pre-activation (scale and shift are finite), run in packed fp16 over the stored hi halves it finds a value
+// that left the fp16 range (hi = +inf). `asm volatile`: as plain compares the checks were sunk behind the tile's last store, with the 112
+// pre-activations of merge_conv_a kept live (a quarter of them in scratch) and an s_waitcnt vmcnt(0) - i.e. a wait for every store in flight -
+// per reload: 21,000 clocks of epilogue per tile where the stores alone take 4,900 (tools/probe/store_probe.hip; SN_TIMING 10, round 3)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sn_track_acc(f32x2_t &c, const f32x4 &a)
+{
+    const f32x2_t lo = __builtin_shufflevector(a, a, 0, 1), hi = __builtin_shufflevector(a, a, 2, 3);
+    asm volatile("v_pk_fma_f32 %0, %1, 0, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "v"(lo));
+    asm volatile("v_pk_fma_f32 %0, %1, 0, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "v"(hi));
+}
+__device__ __forceinline__ void sn_track_h2(unsigned &c, unsigned h2) { asm volatile("v_pk_fma_f16 %0, %1, 0, %0" : "+v"(c) : "v"(h2)); }
+__device__ __forceinline__ bool sn_tracked_bad(const f32x2_t &c, unsigned h) { return !(c.x == 0.f && c.y == 0.f) || (h & 0x7fff7fffu) != 0u; }
 
 // hi/lo split of an fp32 value into two fp16 (hi = rn(y), lo = rn(y - hi)); |y - hi - lo| <= 2^-22 |y|
 __device__ __forceinline__ void sn_split(float y, _Float16 &hi, _Float16 &lo)
@@ -598,6 +613,8 @@ conv3d_f16_mfma(ConvArgs a)
     long long t_vm = 0, t_bar = 0, n_piece = 0, t_mx = 0, t_rel = 0, t_c0 = 0, t_dma = 0;
     const long long t_kernel0 = SN_TIMING ? __builtin_readcyclecounter() : 0;
     bool bad = false;   // a stored value left the fp16 range / is NaN (checked on the fp32 value in the epilogue)
+    f32x2_t trk_acc = {0.f, 0.f};   // ... the store epilogues' form of the same test (sn_track_acc / sn_track_h2)
+    unsigned trk_h = 0;
 
     for (; tile < a.total_tiles; tile += tstride) {
         int b, x0, y0, z0;
@@ -628,6 +645,7 @@ conv3d_f16_mfma(ConvArgs a)
         // two slots of (epilogue + load) each - a group's epilogue sits in its load slot while the partner's short MFMA burst ends and waits -
         // which merge_conv_a's store epilogue cannot afford (+4 % against the non-ping-pong kernel before this, A/B r3e).
         if constexpr (PP && SN_PP_RESYNC) { if (wave >= C::NW / 2) wg_barrier(); }
+        const long long t_tile0 = SN_TIMING == 10 ? __builtin_readcyclecounter() : 0;     // 10: per tile {epilogue, K loop}
         for (int slab = 0; slab < a.nslab; ++slab) {
             const int c8n = a.slab_c8[slab];
             const int nchunk = chunks_of(c8n);
@@ -822,7 +840,7 @@ conv3d_f16_mfma(ConvArgs a)
 #define PP_T(i) do { if constexpr (SN_TIMING) { ppt[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
                     auto pp_account = [&](bool mx) {
                         if constexpr (SN_TIMING) {
-                            if constexpr (SN_TIMING == 9) {
+                            if constexpr (SN_TIMING >= 9) {
                             } else
                             if constexpr (SN_TIMING >= 7) {            // 7: f16 segments, 8: MX segments: {DMA issue 0-a, LDS reads a-1} (the DMAs are issued FIRST in these builds)
                                 if ((SN_TIMING == 8) == mx) { t_vm += ppta - ppt[0]; t_bar += ppt[1] - ppta; ++n_piece; }
@@ -1414,6 +1432,8 @@ conv3d_f16_mfma(ConvArgs a)
         }
 
         if constexpr (PP && SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }     // pairs with group 1's last compute segment of the tile
+        const long long t_tile1 = SN_TIMING == 10 ? __builtin_readcyclecounter() : 0;
+        if constexpr (SN_TIMING == 10) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- epilogue: folded BN affine + activation --------------------------------------------------------
         if constexpr (EPI == EPI_STORE && (SN_ABL & 512)) {
             // ablation 512: keep the accumulators live, store nothing
@@ -1696,7 +1716,8 @@ conv3d_f16_mfma(ConvArgs a)
                 frag_xyz(mp + (odd ? 1 : 0), hx_, hy_, hz_);
                 const int gx = x0 + hx_, gy = y0 + hy_, gz = z0 + hz_;
                 const bool my_valid = gx < DX && gy < D && gz < D;
-                const unsigned my_voff = ((unsigned)((gx * D + gy) * D + gz) + (unsigned)(kq >> 1) * (unsigned)VOL) * 16u;
+                const unsigned my_voff = (SN_ABL & 1024) ? ((unsigned)((hx_ * D + hy_) * D + hz_) + (unsigned)(kq >> 1) * (unsigned)VOL) * 16u   // ablation 1024: every tile writes tile 0's slots (L2-resident)
+                                                         : ((unsigned)((gx * D + gy) * D + gz) + (unsigned)(kq >> 1) * (unsigned)VOL) * 16u;
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
@@ -1714,7 +1735,6 @@ conv3d_f16_mfma(ConvArgs a)
                         for (int r = 0; r < 4; ++r) {
                             const float pre = acc[mp + e][n][r] * sc[r] + sh[r];
                             float y = ACT == 0 ? fmaxf(pre, 0.f) : sn_sigmoid(pre);
-                            bad |= sn_bad_value(pre, y);     // (the pre-activation: ReLU would turn a NaN / -inf accumulator into a clean 0)
                             if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
                                 sn_split(y, hh, ll);
@@ -1726,6 +1746,8 @@ conv3d_f16_mfma(ConvArgs a)
                         }
                         const uint2 hb = __builtin_bit_cast(uint2, h);
                         hw[e][0] = hb.x; hw[e][1] = hb.y;
+                        sn_track_acc(trk_acc, acc[mp + e][n]);       // (the accumulator: ReLU would turn a NaN / -inf one into a clean 0)
+                        sn_track_h2(trk_h, hb.x); sn_track_h2(trk_h, hb.y);
                         if constexpr (OSPLIT == 1) {
                             const uint2 lb = __builtin_bit_cast(uint2, l);
                             lw[e][0] = lb.x; lw[e][1] = lb.y;
@@ -1743,10 +1765,11 @@ conv3d_f16_mfma(ConvArgs a)
                     const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
                     const auto h1 = __builtin_amdgcn_permlane16_swap(hw[0][1], hw[1][1], false, false);
                     const int g0 = (a.out_coff + (blockIdx.y * NF + n) * 16) >> 3;      // first 8-channel group of fragment n (out_coff is a multiple of 8)
-                    char *const plane = reinterpret_cast<char *>(a.out) + 2 * ((size_t)b * VOL * a.out_cs + (size_t)g0 * VOL * 8);     // wave-uniform
+                    char *const plane = reinterpret_cast<char *>(a.out) + 2 * ((size_t)((SN_ABL & 1024) ? 0 : b) * VOL * a.out_cs + (size_t)g0 * VOL * 8);     // wave-uniform
                     _Float16 *o = reinterpret_cast<_Float16 *>(plane + my_voff);
                     const bool st = my_valid && ch_ok;
                     if (st) *reinterpret_cast<u32x4 *>(o) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+                    if constexpr (SN_ABL & 2048) { if (st) { const u32x4 dv = u32x4{h0[0], h1[0], h0[1], h1[1]}; asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(o), "v"(dv) : "memory"); } }   // ablation 2048: every hi-plane store issued twice
                     if constexpr (OSPLIT == 1) {
                         const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
                         const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
@@ -1795,8 +1818,10 @@ conv3d_f16_mfma(ConvArgs a)
                 if (valid && kq == 0) a.out_f32[vox] = sn_sigmoid(t);
             }
         }
+        if constexpr (SN_TIMING == 10) { const long long t_tile2 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_vm += t_tile2 - t_tile1; t_bar += t_tile1 - t_tile0; ++n_piece; }
     }
     if constexpr (PP && !SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }       // pairs with group 1's last compute segment
+    bad |= sn_tracked_bad(trk_acc, trk_h);
     if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, a.status_bit);
     if constexpr (SN_TIMING) {
         if (a.status && lane == 0) {        // [2..9]: per layer-bit slot of 4 x u64: kernel cycles, vmcnt-wait cycles, barrier-wait cycles, pieces (summed over waves)
