@@ -196,10 +196,10 @@ enum { EPI_STORE = 0, EPI_FINAL = 1, EPI_POOL2D = 2, EPI_SIDEPOOL = 3 };   // PO
 
 template <int V> struct IntC { static constexpr int value = V; };
 __device__ __forceinline__ float sn_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// Numeric status of one epilogue value: t = the pre-activation (folded BN of the accumulator), y = what is stored. ReLU maps a NaN or -inf
-// pre-activation to 0, so the test has to look at t: not finite (an accumulator that overflowed or met inf - inf upstream), or y beyond fp16.
-__device__ __forceinline__ bool sn_bad_value(float t, float y) { return !(fabsf(t) <= 3.0e38f) || !(y <= 65504.f); }
-// The store epilogues track the same two conditions with one packed VALU op per PAIR of values instead of two compares and a scalar OR per
+// Numeric status of the values an epilogue stores: the layer fails (status bit, SN_ERR_RANGE) when an ACCUMULATOR is not finite (it overflowed
+// or met inf - inf upstream; ReLU would map a NaN / -inf pre-activation to a clean 0, so the test has to look in front of the activation) or
+// when a stored value leaves the fp16 range (its hi half is +inf).
+// Both conditions are tracked with one packed VALU op per PAIR of values instead of two compares and a scalar OR per
 // value: c = fma(x, 0, c) stays (+-)0 while every x is finite and turns into a sticky NaN at the first +-inf / NaN (inf * 0 = NaN); run over the
 // ACCUMULATORS it finds a non-finite pre-activation (scale and shift are finite), run in packed fp16 over the stored hi halves it finds a value
 // that left the fp16 range (hi = +inf). `asm volatile`: as plain compares the checks were sunk behind the tile's last store, with the 112
@@ -1477,7 +1477,6 @@ conv3d_f16_mfma(ConvArgs a)
                         const float t0 = acc[m][n][r] * sc[r] + sh[r], t1 = R2 ? acc[m + 1 < MF ? m + 1 : m][n][r] * sc[r] + sh[r] : t0;
                         float y = fmaxf(t0, 0.f);
                         if constexpr (R2) y = fmaxf(y, fmaxf(t1, 0.f));
-                        bad |= sn_bad_value(t0, y) || sn_bad_value(t1, y);
                         y = fmaxf(y, __shfl_xor(y, 1));
                         if constexpr (!R2) y = fmaxf(y, __shfl_xor(y, YX));
                         if constexpr (OSPLIT == 1) {
@@ -1489,6 +1488,9 @@ conv3d_f16_mfma(ConvArgs a)
                             lo32[r] = (y - (float)h[r]) * kMxLoMul;
                         }
                     }
+                    sn_track_acc(trk_acc, acc[m][n]);
+                    if constexpr (R2) sn_track_acc(trk_acc, acc[m + 1 < MF ? m + 1 : m][n]);
+                    { const uint2 hb = __builtin_bit_cast(uint2, h); sn_track_h2(trk_h, hb.x); sn_track_h2(trk_h, hb.y); }
                     if (writer && nl < a.out_cp) {
                         const int ch = a.out_coff + nl;
                         _Float16 *o = a.out + (size_t)b * VOLo * a.out_cs + ((size_t)(ch >> 3) * VOLo + vlin) * 8 + (ch & 7);
@@ -1523,9 +1525,10 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pre = acc[m][n][r] * sc[r] + sh[r], t = fmaxf(pre, 0.f);
-                        bad |= sn_bad_value(pre, t);
                         y[m][n][r] = t;
                     }
+#pragma unroll
+                for (int m = 0; m < MF; ++m) sn_track_acc(trk_acc, acc[m][n]);     // (a value beyond fp16 shows up as +inf in the pooled store / the side conv's operand)
             }
             // ---- side conv (1x1x1 over all NF*16 channels) on the matrix cores: B operand = the outputs as this lane holds them
             f32x4 sacc[MF];
@@ -1575,7 +1578,6 @@ conv3d_f16_mfma(ConvArgs a)
                         for (int r = 0; r < 4; ++r) {
                             const float pre = sacc[mp + e][r] * ssc[r] + ssh[r];
                             float t = a.side_act == 0 ? fmaxf(pre, 0.f) : sn_sigmoid(pre);
-                            bad |= sn_bad_value(pre, t);
                             if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
                                 sn_split(t, hh, ll);
@@ -1587,6 +1589,8 @@ conv3d_f16_mfma(ConvArgs a)
                         }
                         const uint2 hb = __builtin_bit_cast(uint2, h);
                         hw[e][0] = hb.x; hw[e][1] = hb.y;
+                        sn_track_acc(trk_acc, sacc[mp + e]);
+                        sn_track_h2(trk_h, hb.x); sn_track_h2(trk_h, hb.y);
                         if constexpr (OSPLIT == 1) {
                             const uint2 lb = __builtin_bit_cast(uint2, l);
                             lw[e][0] = lb.x; lw[e][1] = lb.y;
@@ -1655,6 +1659,7 @@ conv3d_f16_mfma(ConvArgs a)
                         }
                     }
                     const int ch = n * 16 + kq * 4;
+                    { const uint2 hb = __builtin_bit_cast(uint2, h); sn_track_h2(trk_h, hb.x); sn_track_h2(trk_h, hb.y); }
                     if (writer && ch < a.out_cp) {
                         char *const plane = reinterpret_cast<char *>(a.pool_out) + 2 * ((size_t)b * VOLo * a.pool_cs + (size_t)(2 * n) * VOLo * 8);     // wave-uniform
                         _Float16 *o = reinterpret_cast<_Float16 *>(plane + pvoff);
