@@ -133,6 +133,10 @@
 #ifndef SN_PP_RESYNC
 #define SN_PP_RESYNC 1    // ping-pong: re-establish the group offset per tile so that both groups' epilogues overlap (see the tile loop)
 #endif
+#ifndef SN_PP_NOBR
+#define SN_PP_NOBR 2        // ping-pong loops: weight DMAs issued without per-item / per-piece branches (1: f16m8 loop, 2: f16 / f16x3 loop too): a wave
+                            // without an item of its own repeats the piece's last one. merge_conv_a -3..4 %, conv1_x -1.5 %, the rest unchanged (A/B r3w)
+#endif
 #ifndef SN_PP_DESIG
 #define SN_PP_DESIG 0     // ping-pong: one designated wave per load slot issues that slot's weight DMAs (see stage_w_part)
 #endif
@@ -724,6 +728,21 @@ conv3d_f16_mfma(ConvArgs a)
                                 lds_read32<0>(ko_n[j], koff_a + (unsigned)(ch0 + (sc + 1) * SEGC + j) * 16);      // tap offsets of the next segment's chunks
                             });
                             if constexpr (sc == 0) {
+                                if constexpr (SN_PP_NOBR >= 2) {
+                                    // branch-free issue: always the compile-time maximum per wave; an index beyond the piece repeats its last item (same
+                                    // bytes, same place), and behind the layer's last piece its first one is fetched into the idle buffer
+                                    const bool real = w_next;
+                                    const char *src = wsrc0 + (real ? w_off : 0);
+                                    char *dst = wbuf + (wbi ^ 1) * C::WBUF;
+                                    const int nch0 = wchunks_of(a.slab_c8[0]);
+                                    const int cnt = (real ? w_nch : (nch0 < C::PCH ? nch0 : C::PCH)) * NF * NPL;
+                                    constexpr int WPWX = (C::PCH * NF * NPL + C::NW - 1) / C::NW;
+                                    static_for<0, WPWX>([&](auto kc) {
+                                        int i = decltype(kc)::value * C::NW + wave;
+                                        i = i < cnt ? i : cnt - 1;
+                                        dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
+                                    });
+                                } else
                                 if (w_next) {
                                     const char *src = wsrc0 + w_off;
                                     char *dst = wbuf + (wbi ^ 1) * C::WBUF;
@@ -810,7 +829,11 @@ conv3d_f16_mfma(ConvArgs a)
                             for (int j = j0; j < j1; ++j) dma16(src + (size_t)j * 1024 + lane * 16, dst + j * 1024);
                     } else
                     for (int k = k0; k < k1; ++k) {
-                        const int i = k * C::NW + wave;
+                        int i = k * C::NW + wave;
+                        if constexpr (SN_PP_NOBR) {            // branch-free: a wave without an item of its own repeats the piece's last one (same bytes, same place)
+                            i = i < WCNT ? i : WCNT - 1;
+                            dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
+                        } else
                         if (i < WCNT) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
                     }
                 };
@@ -820,8 +843,8 @@ conv3d_f16_mfma(ConvArgs a)
                     const int ch0 = p * C::PCH;
                     const unsigned wp = wbuf_a + wbi * C::WBUF;
                     // the piece after this one: next piece of the slab, else the first piece of the next slab / tile
-                    const bool w_next = (p + 1 < npiece) || have_next;
-                    const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
+                    const bool w_next = SN_PP_NOBR ? true : ((p + 1 < npiece) || have_next);      // (NOBR: behind the last piece of all, piece 0 of the layer is fetched into the idle buffer)
+                    const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : (SN_PP_NOBR && !have_next ? 0 : nwoff);
                     const bool has_B = ch0 + 1 < nchunk;             // (the last piece of a slab with an odd chunk count has no second f16 chunk)
                     int hnow = 0;
                     // SN_PP_HSPREAD: the next slab's halo DMAs are issued one slot of the wave's HT per piece (the slab's last piece takes what is left),

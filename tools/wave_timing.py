@@ -39,6 +39,25 @@ def main():
         for _ in range(steps):
             ctx.cvc_forward_dev(n, n_vp, d[0], d[1], d[2], d[3], d_fused)
         fn(ctx._h, out.ctypes.data_as(ctypes.c_void_p), 32, names, 2048)
+        if "--simil" in sys.argv:                   # the similarityNet's 2-D conv layers (names beyond the 31st share status bit 31 = slot 31)
+            values = weights.synthetic_simil_param_values(0)
+            ctx.load_simil_param_values(values)
+            mean = np.asarray([103.939, 116.779, 123.68], dtype=np.float32)
+            rs = np.random.RandomState(1)
+            H, W = sc["imgs"][0].shape[:2]
+            ch, cw = rs.uniform(0, H, 2040), rs.uniform(0, W, 2040)
+            ctx.crop_embed(0, ch, cw, mean)
+            fn(ctx._h, out.ctypes.data_as(ctypes.c_void_p), 32, names, 2048)
+            for _ in range(steps):
+                ctx.crop_embed(0, ch, cw, mean)
+            fn(ctx._h, out.ctypes.data_as(ctypes.c_void_p), 32, names, 2048)
+            nms = [x for x in names.value.decode().split(",") if x]
+            for i in range(32):
+                k, vm, bar, pieces = (float(v) for v in out[i])
+                if k > 0:
+                    print("%-14s wave-cycles %.3e  column-1 %5.1f %%  column-2 %5.1f %%  pieces %.0f  cycles/piece %.0f  (per piece: %.0f, %.0f)"
+                          % (nms[i] if i < len(nms) else "slot %d (shared)" % i, k, 100 * vm / k, 100 * bar / k, pieces, k / max(pieces, 1), vm / max(pieces, 1), bar / max(pieces, 1)))
+            return
         for i, nm in enumerate([x for x in names.value.decode().split(",") if x]):
             k, vm, bar, pieces = (float(v) for v in out[i])
             if k > 0:
