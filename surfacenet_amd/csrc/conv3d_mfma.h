@@ -133,6 +133,12 @@
 #ifndef SN_PP_RESYNC
 #define SN_PP_RESYNC 1    // ping-pong: re-establish the group offset per tile so that both groups' epilogues overlap (see the tile loop)
 #endif
+#ifndef SN_PP_RSPREAD
+#define SN_PP_RSPREAD 1     // SN_PP_AB: in-burst operand reads one behind each MFMA instead of several behind each group of MF
+#endif
+#ifndef SN_PP_AB
+#define SN_PP_AB 0          // f16m8 ping-pong loop: TWO segments per weight piece (both f16 chunks in one burst | the MX step) instead of three
+#endif
 #ifndef SN_PP_NOBR
 #define SN_PP_NOBR 2        // ping-pong loops: weight DMAs issued without per-item / per-piece branches (1: f16m8 loop, 2: f16 / f16x3 loop too): a wave
                             // without an item of its own repeats the piece's last one. merge_conv_a -3..4 %, conv1_x -1.5 %, the rest unchanged (A/B r3w)
@@ -619,6 +625,13 @@ conv3d_f16_mfma(ConvArgs a)
     bool bad = false;   // a stored value left the fp16 range / is NaN (checked on the fp32 value in the epilogue)
     f32x2_t trk_acc = {0.f, 0.f};   // ... the store epilogues' form of the same test (sn_track_acc / sn_track_h2)
     unsigned trk_h = 0;
+    // SN_PP_AB: the f16 weight fragments of the NEXT piece's first K-chunk are read during the MX burst of the piece before it
+    constexpr bool PPAB = PPM && SN_PP_AB && MF <= NF && NF <= 8 && NW_ == 8 && 3 * (NF - 2) >= MF + NF;     // (wide kernels only: the in-burst operand reads need NF - 2 >= (MF + NF) / 3 MFMA groups)
+    half8 wf0c[PPAB ? NF : 1];
+    if constexpr (PPAB) {
+        static_for<0, NF>([&](auto nc) { constexpr int n = decltype(nc)::value; lds_read128<n * 1024>(wf0c[n], wbuf_a); });
+        lgkm_wait<0>();
+    }
 
     for (; tile < a.total_tiles; tile += tstride) {
         int b, x0, y0, z0;
@@ -830,6 +843,10 @@ conv3d_f16_mfma(ConvArgs a)
                     } else
                     for (int k = k0; k < k1; ++k) {
                         int i = k * C::NW + wave;
+                        // SN_PP_AB: group 0 requests the next piece's first NF fragments from inside its MX burst, i.e. BEFORE group 1 (one slot behind)
+                        // has waited for its share of that piece's DMAs: items 0..7 (NF <= 8: all of them) must be group 0's own
+                        if constexpr (PPAB) i = (k >> 1) * 16 + (wave >> 2) * 8 + (k & 1) * 4 + (wave & 3);
+                        static_assert(!PPAB || WPW % 2 == 0 || WCNT <= (WPW - 1) * 8 + 4, "SN_PP_AB: the permuted DMA duty covers every item");
                         if constexpr (SN_PP_NOBR) {            // branch-free: a wave without an item of its own repeats the piece's last one (same bytes, same place)
                             i = i < WCNT ? i : WCNT - 1;
                             dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
@@ -906,7 +923,11 @@ conv3d_f16_mfma(ConvArgs a)
                             // SN_PP_EARLYBAR: the slot's closing barrier in front of the burst's last MF MFMAs (see the f16 / f16x3 loop)
                             if constexpr (SN_PP_EARLYBAR && n == NF - 1) { if (close) { __builtin_amdgcn_sched_barrier(0); PP_T(3); wg_barrier(); __builtin_amdgcn_sched_barrier(0); } }
 #pragma unroll
-                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);
+                            for (int m = 0; m < ((SN_ABL & 8192) ? MF / 2 : MF); ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);   // (ablation 8192: half bursts)
+                            if constexpr (SN_ABL & 4096) {        // ablation 4096: every burst twice as long (is a slot bounded by the burst or by the partner's load?)
+#pragma unroll
+                                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);
+                            }
                             if constexpr (pre == 1) { lds_read128<(NF + n) * 1024>(wf[1][n], wp); __builtin_amdgcn_sched_barrier(0); }
                             if constexpr (pre == 2) {
                                 if constexpr (n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
@@ -932,6 +953,181 @@ conv3d_f16_mfma(ConvArgs a)
                     using INF = std::integral_constant<int, NF>;
                     constexpr int WSPLIT = PPWIN ? SN_PP_WSPLIT : (WPW + 1) / 2;    // weight DMA instalments [0, WSPLIT) with chunk 2p, [WSPLIT, WPW) with chunk 2p+1
                     static_assert(!(PPWIN && (SN_PP_WPRE || SN_PP_MERGE)), "PPWIN excludes SN_PP_WPRE / SN_PP_MERGE");
+                    if constexpr (PPAB) {
+                        // ---- TWO segments per piece (SN_PP_AB). The ~190 clocks a slot costs beyond its burst (barrier, hand-over) and the LDS reads of a
+                        // load slot (30-40 clocks each for the loading wave, tools/probe/dma_probe.hip) are what the three-segment loop pays three
+                        // times per piece for 3 x 448 clocks of MFMA issue. Here: segment F = BOTH f16 chunks in one burst of 2 * MF * NF MFMAs -
+                        // chunk 2p's weight fragments were read during the previous MX burst (wf0c), its activation fragments in the load slot;
+                        // chunk 2p+1's operands are requested from inside the first half of the burst, the MX step's weights from inside the
+                        // second half - and segment M = the MX step, whose burst requests the NEXT piece's first weight fragments.
+                        static_assert(SN_PP_NOBR >= 1 && !SN_PP_MERGE && !SN_PP_WPRE && !SN_PP_HSPREAD && !SN_PP_EARLYBAR && !SN_PP_DESIG && SN_PP_B128,
+                                      "SN_PP_AB: branch-free weight DMAs, default ping-pong options");
+                        static_assert(SN_TIMING == 0 || SN_TIMING >= 10, "SN_PP_AB: timing modes 10 (per tile), 11 (burst F: {wait for chunk 2p+1's operands, whole burst}), 12 ({load slot F, load slot M}), 13 ({burst M, its closing wait})");
+                        // ---- load slot F: 4 LDS reads, the whole next weight piece's DMAs
+                        const long long tL1 = SN_TIMING == 12 ? __builtin_readcyclecounter() : 0;
+                        load_x(I0{}, koA);
+                        // SN_PP_AB 2: the MX step's activation codes are read HERE, not in load slot M: that slot runs beside the partner's short MX
+                        // burst for one of the two groups (720 against 433 clocks, SN_TIMING 12 / 13), this one beside a burst with room to spare
+                        v8i x8[MF];
+                        v4i x8h[MF][2];
+                        constexpr int XE = SN_PP_AB >= 3 ? MF : (SN_PP_AB == 2 ? MF / 2 : 0);      // fragments read early (all of them: register spills in the NF = 7 kernels)
+                        if constexpr (SN_PP_AB >= 2) {
+                            const unsigned ks0 = xslab + C::XPLANE + (unsigned)(int)k2, ks1 = xslab + C::XPLANE + (unsigned)(int)(k2 >> 32);
+                            static_for<0, XE>([&](auto mc) {
+                                constexpr int m = decltype(mc)::value;
+                                lds_read128i<0>(x8h[m][0], (unsigned)xbase[m] + ks0);
+                                lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
+                            });
+                        }
+                        stage_w_part(w_off, wbi ^ 1, 0, WPW);
+                        lgkm_wait<0>();
+                        if constexpr (SN_PP_AB >= 2) {
+#pragma unroll
+                            for (int m = 0; m < XE; ++m) {
+                                asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
+                                x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
+                            }
+#pragma unroll
+                            for (int m = 0; m < XE; ++m) asm volatile("" : "+v"(x8[m]));
+                        }
+                        if constexpr (SN_TIMING == 12) { t_vm += __builtin_readcyclecounter() - tL1; ++n_piece; }
+                        wg_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        const long long tC1 = SN_TIMING == 11 ? __builtin_readcyclecounter() : 0;
+                        {
+                            const unsigned kosB = xslab + (unsigned)koB;
+                            constexpr int RPG = 3;                         // operand reads of chunk 2p+1 per MFMA group: all MF + NF of them behind the first 4 groups
+                            static_assert(RPG * (NF - 2) >= MF + NF, "in-burst operand reads");
+                            static_for<0, NF>([&](auto nc) {
+                                constexpr int n = decltype(nc)::value;
+                                static_for<0, MF>([&](auto mc) {
+                                    constexpr int m = decltype(mc)::value;
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0c[n], xf[0][m], acc[m][n], 0, 0, 0);
+                                    if constexpr (SN_PP_RSPREAD) {        // one read behind every other MFMA (the next MFMA waits for the pipe anyway: a read that
+                                        constexpr int i = n * MF + m;      // stalls on a full LDS queue then delays nothing) instead of RPG behind each group of MF;
+                                        if constexpr (i % 2 == 1) {        // (behind EVERY one: the operands of chunk 2p+1 turn live too early - spills)
+                                            constexpr int r = i / 2;
+                                            if constexpr (r < MF) lds_read128<0>(xf[1][r], (unsigned)xbase[r] + kosB);
+                                            else if constexpr (r < MF + NF) lds_read128<(NF + (r - MF)) * 1024>(wf[1][r - MF], wp);
+                                        }
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    }
+                                });
+                                if constexpr (!SN_PP_RSPREAD)
+                                static_for<0, RPG>([&](auto jc) {
+                                    constexpr int r = n * RPG + decltype(jc)::value;
+                                    if constexpr (r < MF) lds_read128<0>(xf[1][r], (unsigned)xbase[r] + kosB);
+                                    else if constexpr (r < MF + NF) lds_read128<(NF + (r - MF)) * 1024>(wf[1][r - MF], wp);
+                                });
+                                __builtin_amdgcn_sched_barrier(0);
+                            });
+                            if (has_B) {
+                                const long long tW = SN_TIMING == 11 ? __builtin_readcyclecounter() : 0;
+                                lgkm_wait<0>();
+                                if constexpr (SN_TIMING == 11) { t_vm += __builtin_readcyclecounter() - tW; ++n_piece; }
+                                static_for<0, NF>([&](auto nc) {
+                                    constexpr int n = decltype(nc)::value;
+                                    static_for<0, MF>([&](auto mc) {
+                                        constexpr int m = decltype(mc)::value;
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][n], xf[1][m], acc[m][n], 0, 0, 0);
+                                        if constexpr (SN_PP_RSPREAD) {
+                                            if constexpr (m == 0) lds_read128i<mxo + n * 2048>(wa4[n], wp);
+                                            if constexpr (m == 1) lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
+                                            if constexpr (m == 2 && n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
+                                            __builtin_amdgcn_sched_barrier(0);
+                                        }
+                                    });
+                                    if constexpr (!SN_PP_RSPREAD) {
+                                        if constexpr (n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
+                                        lds_read128i<mxo + n * 2048>(wa4[n], wp);
+                                        lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                });
+                            } else {
+                                load_mxw(I0{}, INF{});
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (SN_TIMING == 11) { if (has_B) t_bar += __builtin_readcyclecounter() - tC1; }
+                        wg_barrier();
+                        const long long tL2 = SN_TIMING == 12 ? __builtin_readcyclecounter() : 0;
+                        // ---- load slot M: the activation codes, next piece's tap offsets; DMA: the next slab's halo tile and tap table (first piece of a slab)
+                        {
+                            int koAn = 0, koBn = 0;
+                            long long k2n = 0;
+                            if constexpr (XE < MF) {
+                                const unsigned ks0 = xslab + C::XPLANE + (unsigned)(int)k2, ks1 = xslab + C::XPLANE + (unsigned)(int)(k2 >> 32);
+                                static_for<XE, MF>([&](auto mc) {
+                                    constexpr int m = decltype(mc)::value;
+                                    lds_read128i<0>(x8h[m][0], (unsigned)xbase[m] + ks0);
+                                    lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
+                                });
+                            }
+                            if (p + 1 < npiece) {
+                                lds_read32<0>(koAn, koff_a + (unsigned)(ch0 + 2) * 16);
+                                lds_read32<0>(koBn, koff_a + (unsigned)(ch0 + 3) * 16);
+                                lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
+                            }
+                            if (p == 0 && have_next && !(SN_ABL & 1)) {
+                                hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                                if (wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                            }
+                            // the next weight piece (issued one load slot ago) has landed; this slab's halo DMAs, just issued, may still fly
+                            if (p + 1 < npiece && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
+                            else if (p + 1 < npiece && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            lgkm_wait<0>();
+                            v8i wa[NF];
+                            if constexpr (XE < MF) {
+#pragma unroll
+                                for (int m = XE; m < MF; ++m) {
+                                    asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
+                                    x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
+                                }
+                            }
+#pragma unroll
+                            for (int n = 0; n < NF; ++n) {
+                                const v2i_ b2 = __builtin_bit_cast(v2i_, wb2[n]);
+                                const v4i b4 = __builtin_shufflevector(b2, b2, 0, 1, -1, -1);
+                                wa[n] = __builtin_shufflevector(wa4[n], b4, 0, 1, 2, 3, 4, 5, -1, -1);
+                            }
+                            if (p + 1 < npiece) { koA = koAn; koB = koBn; k2 = k2n; }
+#pragma unroll
+                            for (int m = 0; m < MF; ++m) asm volatile("" : "+v"(x8[m]));
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (SN_TIMING == 12) t_bar += __builtin_readcyclecounter() - tL2;
+                            wg_barrier();
+                            __builtin_amdgcn_sched_barrier(0);
+                            const long long tC2 = SN_TIMING == 13 ? __builtin_readcyclecounter() : 0;
+                            const unsigned wpn = wbuf_a + (wbi ^ 1) * C::WBUF;          // the piece after this one
+                            static_for<0, NF>([&](auto nc) {
+                                constexpr int n = decltype(nc)::value;
+                                const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
+                                // the next piece's first weight fragments: all NF requested before the burst's last groups, so that the wait behind the
+                                // burst is free and the registers hold real data wherever the compiler may copy them at a loop edge
+                                static_for<0, MF>([&](auto mc) {
+                                    constexpr int m = decltype(mc)::value;
+                                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
+                                    if constexpr (SN_PP_RSPREAD) {
+                                        constexpr int r = n * MF + m;
+                                        if constexpr (r < NF) lds_read128<r * 1024>(wf0c[r], wpn);
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    }
+                                });
+                                if constexpr (!SN_PP_RSPREAD)
+                                static_for<0, 2>([&](auto jc) {
+                                    constexpr int r = n * 2 + decltype(jc)::value;
+                                    if constexpr (r < NF) lds_read128<r * 1024>(wf0c[r], wpn);
+                                });
+                                __builtin_amdgcn_sched_barrier(0);
+                            });
+                            const long long tC2w = SN_TIMING == 13 ? __builtin_readcyclecounter() : 0;
+                            lgkm_wait<0>();
+                            if constexpr (SN_TIMING == 13) { const long long te = __builtin_readcyclecounter(); t_vm += tC2w - tC2; t_bar += te - tC2w; ++n_piece; }
+                            wg_barrier();
+                        }
+                    } else {
                     if constexpr (SN_PP_MERGE) {
                         // ---- segment F: both f16 chunks of the piece, 2 * MF * NF MFMAs in one burst; DMA: the next weight piece; tap table of the next slab
                         PP_T(0);
@@ -1085,14 +1281,20 @@ conv3d_f16_mfma(ConvArgs a)
                             const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
                             if constexpr (SN_PP_EARLYBAR && n == NF - 1) { __builtin_amdgcn_sched_barrier(0); PP_T(3); wg_barrier(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-                            for (int m = 0; m < MF; ++m)
+                            for (int m = 0; m < ((SN_ABL & 8192) ? MF / 2 : MF); ++m)
                                 acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
+                            if constexpr (SN_ABL & 4096) {
+#pragma unroll
+                                for (int m = 0; m < MF; ++m)
+                                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
+                            }
                         });
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
                         PP_T(4);
                         pp_account(true);
                     }
+                    }     // !SN_PP_AB
 #undef PP_T
 #undef PP_TA
                     wbi ^= 1;
