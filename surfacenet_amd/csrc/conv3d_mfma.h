@@ -965,7 +965,7 @@ conv3d_f16_mfma(ConvArgs a)
                         static_assert(SN_TIMING == 0 || SN_TIMING >= 10, "SN_PP_AB: timing modes 10 (per tile), 11 (burst F: {wait for chunk 2p+1's operands, whole burst}), 12 ({load slot F, load slot M}), 13 ({burst M, its closing wait})");
                         // ---- load slot F: 4 LDS reads, the whole next weight piece's DMAs
                         const long long tL1 = SN_TIMING == 12 ? __builtin_readcyclecounter() : 0;
-                        load_x(I0{}, koA);
+                        if constexpr (!(SN_ABL & 32768)) load_x(I0{}, koA);
                         // SN_PP_AB 2: the MX step's activation codes are read HERE, not in load slot M: that slot runs beside the partner's short MX
                         // burst for one of the two groups (720 against 433 clocks, SN_TIMING 12 / 13), this one beside a burst with room to spare
                         v8i x8[MF];
@@ -979,7 +979,7 @@ conv3d_f16_mfma(ConvArgs a)
                                 lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
                             });
                         }
-                        stage_w_part(w_off, wbi ^ 1, 0, WPW);
+                        if constexpr (!(SN_ABL & 65536)) stage_w_part(w_off, wbi ^ 1, 0, WPW);
                         lgkm_wait<0>();
                         if constexpr (SN_PP_AB >= 2) {
 #pragma unroll
@@ -1005,7 +1005,7 @@ conv3d_f16_mfma(ConvArgs a)
                                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0c[n], xf[0][m], acc[m][n], 0, 0, 0);
                                     if constexpr (SN_PP_RSPREAD) {        // one read behind every other MFMA (the next MFMA waits for the pipe anyway: a read that
                                         constexpr int i = n * MF + m;      // stalls on a full LDS queue then delays nothing) instead of RPG behind each group of MF;
-                                        if constexpr (i % 2 == 1) {        // (behind EVERY one: the operands of chunk 2p+1 turn live too early - spills)
+                                        if constexpr (i % 2 == 1 && !(SN_ABL & 16384)) {        // (behind EVERY one: the operands of chunk 2p+1 turn live too early - spills)
                                             constexpr int r = i / 2;
                                             if constexpr (r < MF) lds_read128<0>(xf[1][r], (unsigned)xbase[r] + kosB);
                                             else if constexpr (r < MF + NF) lds_read128<(NF + (r - MF)) * 1024>(wf[1][r - MF], wp);
@@ -1013,7 +1013,7 @@ conv3d_f16_mfma(ConvArgs a)
                                         __builtin_amdgcn_sched_barrier(0);
                                     }
                                 });
-                                if constexpr (!SN_PP_RSPREAD)
+                                if constexpr (!SN_PP_RSPREAD && !(SN_ABL & 16384))
                                 static_for<0, RPG>([&](auto jc) {
                                     constexpr int r = n * RPG + decltype(jc)::value;
                                     if constexpr (r < MF) lds_read128<0>(xf[1][r], (unsigned)xbase[r] + kosB);
@@ -1030,14 +1030,14 @@ conv3d_f16_mfma(ConvArgs a)
                                     static_for<0, MF>([&](auto mc) {
                                         constexpr int m = decltype(mc)::value;
                                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][n], xf[1][m], acc[m][n], 0, 0, 0);
-                                        if constexpr (SN_PP_RSPREAD) {
+                                        if constexpr (SN_PP_RSPREAD && !(SN_ABL & 16384)) {
                                             if constexpr (m == 0) lds_read128i<mxo + n * 2048>(wa4[n], wp);
                                             if constexpr (m == 1) lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
                                             if constexpr (m == 2 && n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
                                             __builtin_amdgcn_sched_barrier(0);
                                         }
                                     });
-                                    if constexpr (!SN_PP_RSPREAD) {
+                                    if constexpr (!SN_PP_RSPREAD && !(SN_ABL & 16384)) {
                                         if constexpr (n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
                                         lds_read128i<mxo + n * 2048>(wa4[n], wp);
                                         lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
@@ -1056,7 +1056,7 @@ conv3d_f16_mfma(ConvArgs a)
                         {
                             int koAn = 0, koBn = 0;
                             long long k2n = 0;
-                            if constexpr (XE < MF) {
+                            if constexpr (XE < MF && !(SN_ABL & 32768)) {
                                 const unsigned ks0 = xslab + C::XPLANE + (unsigned)(int)k2, ks1 = xslab + C::XPLANE + (unsigned)(int)(k2 >> 32);
                                 static_for<XE, MF>([&](auto mc) {
                                     constexpr int m = decltype(mc)::value;
@@ -1069,7 +1069,7 @@ conv3d_f16_mfma(ConvArgs a)
                                 lds_read32<0>(koBn, koff_a + (unsigned)(ch0 + 3) * 16);
                                 lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
                             }
-                            if (p == 0 && have_next && !(SN_ABL & 1)) {
+                            if (p == 0 && have_next && !(SN_ABL & (1 | 65536))) {
                                 hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
                                 if (wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
                             }
@@ -1109,13 +1109,13 @@ conv3d_f16_mfma(ConvArgs a)
                                 static_for<0, MF>([&](auto mc) {
                                     constexpr int m = decltype(mc)::value;
                                     acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
-                                    if constexpr (SN_PP_RSPREAD) {
+                                    if constexpr (SN_PP_RSPREAD && !(SN_ABL & 16384)) {
                                         constexpr int r = n * MF + m;
                                         if constexpr (r < NF) lds_read128<r * 1024>(wf0c[r], wpn);
                                         __builtin_amdgcn_sched_barrier(0);
                                     }
                                 });
-                                if constexpr (!SN_PP_RSPREAD)
+                                if constexpr (!SN_PP_RSPREAD && !(SN_ABL & 16384))
                                 static_for<0, 2>([&](auto jc) {
                                     constexpr int r = n * 2 + decltype(jc)::value;
                                     if constexpr (r < NF) lds_read128<r * 1024>(wf0c[r], wpn);
