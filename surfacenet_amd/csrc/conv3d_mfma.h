@@ -103,8 +103,10 @@
 #define SN_DMA_LATE 0     // issue the piece's DMAs behind its first MFMA group instead of in front of it: measured null (r2x: +-0.3 %, 30-step A/B)
 #endif
 #ifndef SN_TIMING
-#define SN_TIMING 0       // diagnostic build: per-wave shader-clock totals (whole kernel, vmcnt wait, barrier wait) added into a.status[1..] (results stay valid);
-                          // 3..6 (f16m8 kernels): the two wait slots hold segment times of a weight piece instead, see the piece loop
+#define SN_TIMING 0       // diagnostic build: per-wave shader-clock totals (whole kernel + two columns) added into a.status[1..] (results stay valid). 1: {vmcnt wait,
+                          // barrier wait} per piece (pipelined loop) / {load, wait} per segment (ping-pong f16m8 loop); 2: {burst, wait}; 3..6: the same for the MX /
+                          // the f16 segments only; 7 / 8: sub-piece times of the pipelined loop; 9: the MX segments' vmcnt wait; 10: per TILE {epilogue, K loop}
+                          // (tools/wave_timing.py)
 #endif
 #ifndef SN_PP
 #define SN_PP 1           // 1: ping-pong K loop for the f16m8 3x3x3 kernels (merge_conv_a / merge_conv_b), see the slab loop
@@ -118,12 +120,6 @@
 #ifndef SN_PPX_SEGC
 #define SN_PPX_SEGC 1     // 2: two K-chunks per ping-pong segment where a chunk is a short burst (MF * NF <= 8: conv1_x)
 #endif
-#ifndef SN_PP_MERGE
-#define SN_PP_MERGE 0     // ping-pong: the two f16 chunks of a weight piece form ONE segment (2 * MF * NF MFMAs per burst, one barrier pair less per piece)
-#endif
-#ifndef SN_PP_WPRE
-#define SN_PP_WPRE 0      // ping-pong: the MX step's weight fragments are read in the load segments of the f16 chunks (1: all with the second, 2: split)
-#endif
 #ifndef SN_PP_WIN
 #define SN_PP_WIN 1       // ping-pong: the next segment's weight fragments are read from inside the MFMA burst (see compute_f16); 1: EPI_FINAL kernels, 2: all
 #endif
@@ -133,27 +129,9 @@
 #ifndef SN_PP_RESYNC
 #define SN_PP_RESYNC 1    // ping-pong: re-establish the group offset per tile so that both groups' epilogues overlap (see the tile loop)
 #endif
-#ifndef SN_PP_RSPREAD
-#define SN_PP_RSPREAD 1     // SN_PP_AB: in-burst operand reads one behind each MFMA instead of several behind each group of MF
-#endif
-#ifndef SN_PP_AB
-#define SN_PP_AB 0          // f16m8 ping-pong loop: TWO segments per weight piece (both f16 chunks in one burst | the MX step) instead of three
-#endif
 #ifndef SN_PP_NOBR
 #define SN_PP_NOBR 2        // ping-pong loops: weight DMAs issued without per-item / per-piece branches (1: f16m8 loop, 2: f16 / f16x3 loop too): a wave
                             // without an item of its own repeats the piece's last one. merge_conv_a -3..4 %, conv1_x -1.5 %, the rest unchanged (A/B r3w)
-#endif
-#ifndef SN_PP_DESIG
-#define SN_PP_DESIG 0     // ping-pong: one designated wave per load slot issues that slot's weight DMAs (see stage_w_part)
-#endif
-#ifndef SN_PP_HSPREAD
-#define SN_PP_HSPREAD 0   // ping-pong: halo DMAs of the next slab spread over the slab's pieces (see halo_instalment)
-#endif
-#ifndef SN_PP_EARLYBAR
-#define SN_PP_EARLYBAR 0  // ping-pong: a slot's closing barrier in front of the burst's last MF MFMAs instead of behind them
-#endif
-#ifndef SN_PP_B128
-#define SN_PP_B128 1      // ping-pong MX segment: read the activation code slots whole (ds_read_b128) instead of their 12 code bytes (ds_read_b96)
 #endif
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
@@ -625,13 +603,6 @@ conv3d_f16_mfma(ConvArgs a)
     bool bad = false;   // a stored value left the fp16 range / is NaN (checked on the fp32 value in the epilogue)
     f32x2_t trk_acc = {0.f, 0.f};   // ... the store epilogues' form of the same test (sn_track_acc / sn_track_h2)
     unsigned trk_h = 0;
-    // SN_PP_AB: the f16 weight fragments of the NEXT piece's first K-chunk are read during the MX burst of the piece before it
-    constexpr bool PPAB = PPM && SN_PP_AB && MF <= NF && NF <= 8 && NW_ == 8 && 3 * (NF - 2) >= MF + NF;     // (wide kernels only: the in-burst operand reads need NF - 2 >= (MF + NF) / 3 MFMA groups)
-    half8 wf0c[PPAB ? NF : 1];
-    if constexpr (PPAB) {
-        static_for<0, NF>([&](auto nc) { constexpr int n = decltype(nc)::value; lds_read128<n * 1024>(wf0c[n], wbuf_a); });
-        lgkm_wait<0>();
-    }
 
     for (; tile < a.total_tiles; tile += tstride) {
         int b, x0, y0, z0;
@@ -807,12 +778,14 @@ conv3d_f16_mfma(ConvArgs a)
                 // registers, plus this wave's share of the DMA issue - and then COMPUTED as one uninterrupted burst of MF*NF MFMAs whose operands are
                 // all in registers; a workgroup barrier separates the two, and group 1 runs exactly one barrier behind group 0, so on every SIMD
                 // one wave computes while its partner loads. Nothing is software-pipelined inside a wave: the latency of the LDS reads, the
-                // address arithmetic, the DMA issue, the register shuffles of the 6-bit operands all sit in the load segment, which is shorter
-                // than the partner's compute burst. Buffer recycling needs no barrier of its own: the last reader of a weight piece / halo
-                // buffer (group 1, loading the piece's last segment) has waited for its reads before the barrier that precedes the first
-                // load slot of the next piece, where the refill DMAs are issued.
+                // address arithmetic, the DMA issue, the register shuffles of the 6-bit operands all sit in the load segment. Buffer recycling
+                // needs no barrier of its own: the last reader of a weight piece / halo buffer (group 1, loading the piece's last segment) has
+                // waited for its reads before the barrier that precedes the first load slot of the next piece, where the refill DMAs are issued.
+                // Measured and dropped again (DESIGN.md sections 4.2 / 8; the code is in the history of this file): one designated DMA wave per slot,
+                // halo DMAs spread over the pieces, the closing barrier in front of the burst's last MFMAs, both f16 chunks loaded in one slot,
+                // MX weights read with the f16 chunks' loads, 96-bit reads of the code slots, a two-segment piece (both f16 chunks in one burst).
                 static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_FMT != 0 && SN_MX_B128 && BUFH, "ping-pong loop: f16m8 kernels with 6-bit MX operands");
-                // in-burst weight prefetch: merge_conv_b -2..3 %, but merge_conv_a (store epilogue, spills) +15 % (A/B r3e-r3i) -> EPI_FINAL kernels only
+                // in-burst weight prefetch: merge_conv_b -2..3 %; merge_conv_a +15 % while its epilogue spilled, +0.5 % since (A/B r3e-r3i, r3w) -> EPI_FINAL kernels only
                 constexpr int PPWIN = (SN_PP_WIN == 2 || (SN_PP_WIN == 1 && EPI == EPI_FINAL)) ? 1 : 0;
                 const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
                 const unsigned k2_a = koff_a + kq * 4;
@@ -825,28 +798,12 @@ conv3d_f16_mfma(ConvArgs a)
                 lgkm_wait<0>();
                 constexpr int WCNT = C::PCH * NF * NPL;                     // 1 KiB DMAs per weight piece
                 constexpr int WPW = (WCNT + C::NW - 1) / C::NW;             // ... per wave
-                int desig = slab;                        // rotates the DMA duty over the waves of a group
-                // SN_PP_DESIG: the LDS-DMAs of a load slot are issued by ONE wave of the loading group (rotating), the piece's WCNT items dealt to
-                // the four slots {group 0, group 1} x {chunk 2p, chunk 2p+1}. Issued by all four loading waves at once they queue on the CU's one
-                // texture-addresser (1 KiB = 16 clocks at 64 B/clk): measured 140-190 clocks per instruction and wave (SN_TIMING 7/8), i.e. every
-                // wave pays for everybody's; one wave pays 16 clocks per item and the other three nothing.
+                // items [k0, k1) of this wave's share of the piece at byte offset `off` of the weight stream, into weight buffer wb
                 auto stage_w_part = [&](size_t off, int wb, int k0, int k1) {
                     const char *src = wsrc0 + off;
                     char *dst = wbuf + wb * C::WBUF;
-                    if constexpr (SN_PP_DESIG) {
-                        // k0 == 0: the first f16 chunk's slot (quarters 0, 1 = group 0, 1), else the second's (quarters 2, 3); k1 == WPW with k0 == 0
-                        // (piece without a second chunk): halves instead of quarters
-                        const int grp = wave >> 2, nq = (k0 == 0 && k1 == WPW) ? 2 : 4, q = (k0 == 0 ? 0 : 2) + grp;
-                        const int j0 = (WCNT * (nq == 2 ? grp : q)) / nq, j1 = (WCNT * ((nq == 2 ? grp : q) + 1)) / nq;
-                        if ((wave & 3) == (desig & 3))
-                            for (int j = j0; j < j1; ++j) dma16(src + (size_t)j * 1024 + lane * 16, dst + j * 1024);
-                    } else
                     for (int k = k0; k < k1; ++k) {
                         int i = k * C::NW + wave;
-                        // SN_PP_AB: group 0 requests the next piece's first NF fragments from inside its MX burst, i.e. BEFORE group 1 (one slot behind)
-                        // has waited for its share of that piece's DMAs: items 0..7 (NF <= 8: all of them) must be group 0's own
-                        if constexpr (PPAB) i = (k >> 1) * 16 + (wave >> 2) * 8 + (k & 1) * 4 + (wave & 3);
-                        static_assert(!PPAB || WPW % 2 == 0 || WCNT <= (WPW - 1) * 8 + 4, "SN_PP_AB: the permuted DMA duty covers every item");
                         if constexpr (SN_PP_NOBR) {            // branch-free: a wave without an item of its own repeats the piece's last one (same bytes, same place)
                             i = i < WCNT ? i : WCNT - 1;
                             dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
@@ -855,8 +812,7 @@ conv3d_f16_mfma(ConvArgs a)
                     }
                 };
                 int p = 0;
-                do {
-                    ++desig;                                     // (do-while: a possible zero-trip path made hipcc spill 88 accumulator registers around the loop)
+                do {             // (do-while: a possible zero-trip path made hipcc spill 88 accumulator registers around the loop)
                     const int ch0 = p * C::PCH;
                     const unsigned wp = wbuf_a + wbi * C::WBUF;
                     // the piece after this one: next piece of the slab, else the first piece of the next slab / tile
@@ -864,27 +820,14 @@ conv3d_f16_mfma(ConvArgs a)
                     const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : (SN_PP_NOBR && !have_next ? 0 : nwoff);
                     const bool has_B = ch0 + 1 < nchunk;             // (the last piece of a slab with an odd chunk count has no second f16 chunk)
                     int hnow = 0;
-                    // SN_PP_HSPREAD: the next slab's halo DMAs are issued one slot of the wave's HT per piece (the slab's last piece takes what is left),
-                    // with the piece's second f16 chunk, instead of all HT in the first piece's MX load segment (4 x ~190 clocks in ONE slot)
-                    auto halo_instalment = [&]() {
-                        if constexpr (SN_PP_HSPREAD) {
-                            if (have_next && !(SN_ABL & 1))
-                                stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1,
-                                               p, p + 1 == npiece ? (1 << 20) : p + 1);
-                        }
-                    };
                     // SN_TIMING (diagnostic builds): shader-clock stamps 0 segment start | 1 operands landed | 2 barrier released | 3 MFMAs issued | 4 barrier released;
-                    // odd values accumulate {load 0-1, wait 1-2}, even {compute 2-3, wait 3-4}; 1/2 all segments, 3/4 MX segments only, 5/6 f16 segments only
-                    long long ppt[5] = {0, 0, 0, 0, 0}, ppta = 0;
-#define PP_TA() do { if constexpr (SN_TIMING == 7 || SN_TIMING == 8) { ppta = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
+                    // odd values accumulate {load 0-1, wait 1-2}, even {compute 2-3, wait 3-4}; 1/2 all segments, 3/4 MX segments only, 5/6 f16 segments only.
+                    // (a stamp's lgkmcnt(0) also waits for the wave's in-flight prefetch reads: the "load" figure of a segment that follows an in-burst
+                    // prefetch contains their tail - that is how an LDS-DMA instruction once seemed to cost 140-190 clocks; dma_probe: 19-47)
+                    long long ppt[5] = {0, 0, 0, 0, 0};
 #define PP_T(i) do { if constexpr (SN_TIMING) { ppt[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
                     auto pp_account = [&](bool mx) {
-                        if constexpr (SN_TIMING) {
-                            if constexpr (SN_TIMING >= 9) {
-                            } else
-                            if constexpr (SN_TIMING >= 7) {            // 7: f16 segments, 8: MX segments: {DMA issue 0-a, LDS reads a-1} (the DMAs are issued FIRST in these builds)
-                                if ((SN_TIMING == 8) == mx) { t_vm += ppta - ppt[0]; t_bar += ppt[1] - ppta; ++n_piece; }
-                            } else
+                        if constexpr (SN_TIMING >= 1 && SN_TIMING <= 6) {
                             if ((SN_TIMING <= 2) || ((SN_TIMING <= 4) == mx)) {
                                 if (SN_TIMING & 1) { t_vm += ppt[1] - ppt[0]; t_bar += ppt[2] - ppt[1]; }
                                 else { t_vm += ppt[3] - ppt[2]; t_bar += ppt[4] - ppt[3]; }
@@ -897,31 +840,34 @@ conv3d_f16_mfma(ConvArgs a)
                     v4i wa4[NF];                                    // MX step: a lane's 192-bit weight operand = 128 + 64 bits ...
                     long long wb2[NF], wsc;                         // ... and the E8M0 block scales of its NF fragments
                     typedef int v2i_ __attribute__((ext_vector_type(2)));
-                    auto load_f16 = [&](auto ccc, int ko) {
+                    using I0 = std::integral_constant<int, 0>;
+                    using I1 = std::integral_constant<int, 1>;
+                    using I2 = std::integral_constant<int, 2>;
+                    auto load_x = [&](auto ccc, int ko) {             // the activation fragments of f16 chunk cc
                         constexpr int cc = decltype(ccc)::value;
                         const unsigned kos = xslab + (unsigned)ko;
                         static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<0>(xf[cc][m], (unsigned)xbase[m] + kos); });
+                    };
+                    auto load_f16 = [&](auto ccc, int ko) {           // ... and its weight fragments
+                        constexpr int cc = decltype(ccc)::value;
+                        load_x(ccc, ko);
                         static_for<0, NF>([&](auto nc) { constexpr int n = decltype(nc)::value; lds_read128<(cc * NF + n) * 1024>(wf[cc][n], wp); });
                     };
-                    auto load_mxw = [&](auto n0c, auto n1c) {        // MX weight fragments [n0, n1) (and the scales with fragment 0)
-                        constexpr int n0 = decltype(n0c)::value, n1 = decltype(n1c)::value;
-                        if constexpr (n0 == 0 && n1 > 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
-                        static_for<n0, n1>([&](auto nc) {
+                    auto load_mxw = [&]() {                           // the MX weight fragments and their scales
+                        lds_read64<mxo + 1024 + 8>(wsc, wp);
+                        static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
                             lds_read128i<mxo + n * 2048>(wa4[n], wp);
                             lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
                         });
                     };
                     // PPWIN: the NEXT segment's weight fragments are requested from inside this burst, one fragment behind every group of MF MFMAs
-                    // (pre: 0 none | 1 the f16 fragments of chunk 2p+1 | 2 the MX step's): an LDS read costs a loading wave ~25 clocks (four waves
-                    // queueing on the LDS while the partners' MFMAs own the register-file ports) but a computing wave only its issue slot, of which
-                    // three in four are idle during the burst. The reads land during the wave's next load segment, whose lgkmcnt(0) covers them.
-                    auto compute_f16 = [&](auto ccc, auto prec, bool close = true) {
+                    // (pre: 0 none | 1 the f16 fragments of chunk 2p+1 | 2 the MX step's): an LDS read costs a loading wave 25-40 clocks of its load
+                    // slot (dma_probe), a computing wave ~10 of its burst. The reads land during the wave's next load segment, whose lgkmcnt(0) covers them.
+                    auto compute_f16 = [&](auto ccc, auto prec) {
                         constexpr int cc = decltype(ccc)::value, pre = decltype(prec)::value;
                         static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
-                            // SN_PP_EARLYBAR: the slot's closing barrier in front of the burst's last MF MFMAs (see the f16 / f16x3 loop)
-                            if constexpr (SN_PP_EARLYBAR && n == NF - 1) { if (close) { __builtin_amdgcn_sched_barrier(0); PP_T(3); wg_barrier(); __builtin_amdgcn_sched_barrier(0); } }
 #pragma unroll
                             for (int m = 0; m < ((SN_ABL & 8192) ? MF / 2 : MF); ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);   // (ablation 8192: half bursts)
                             if constexpr (SN_ABL & 4096) {        // ablation 4096: every burst twice as long (is a slot bounded by the burst or by the partner's load?)
@@ -937,305 +883,63 @@ conv3d_f16_mfma(ConvArgs a)
                             }
                         });
                     };
-                    using I2 = std::integral_constant<int, 2>;
-                    auto load_x = [&](auto ccc, int ko) {             // PPWIN: the activation fragments only
-                        constexpr int cc = decltype(ccc)::value;
-                        const unsigned kos = xslab + (unsigned)ko;
-                        static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<0>(xf[cc][m], (unsigned)xbase[m] + kos); });
-                    };
-                    using I0 = std::integral_constant<int, 0>;
-                    using I1 = std::integral_constant<int, 1>;
-                    // MX weight fragments read ahead, in the load segments of the f16 chunks: SN_PP_WPRE 0 none | 1 all with chunk 2p+1 (or the merged
-                    // segment) | 2 NFA with chunk 2p, the rest with chunk 2p+1
-                    constexpr int NFA = SN_PP_WPRE == 2 ? (NF + 1) / 2 : 0, NFB = SN_PP_WPRE ? NF : 0;
-                    using INFA = std::integral_constant<int, NFA>;
-                    using INFB = std::integral_constant<int, NFB>;
-                    using INF = std::integral_constant<int, NF>;
                     constexpr int WSPLIT = PPWIN ? SN_PP_WSPLIT : (WPW + 1) / 2;    // weight DMA instalments [0, WSPLIT) with chunk 2p, [WSPLIT, WPW) with chunk 2p+1
-                    static_assert(!(PPWIN && (SN_PP_WPRE || SN_PP_MERGE)), "PPWIN excludes SN_PP_WPRE / SN_PP_MERGE");
-                    if constexpr (PPAB) {
-                        // ---- TWO segments per piece (SN_PP_AB). The ~190 clocks a slot costs beyond its burst (barrier, hand-over) and the LDS reads of a
-                        // load slot (30-40 clocks each for the loading wave, tools/probe/dma_probe.hip) are what the three-segment loop pays three
-                        // times per piece for 3 x 448 clocks of MFMA issue. Here: segment F = BOTH f16 chunks in one burst of 2 * MF * NF MFMAs -
-                        // chunk 2p's weight fragments were read during the previous MX burst (wf0c), its activation fragments in the load slot;
-                        // chunk 2p+1's operands are requested from inside the first half of the burst, the MX step's weights from inside the
-                        // second half - and segment M = the MX step, whose burst requests the NEXT piece's first weight fragments.
-                        static_assert(SN_PP_NOBR >= 1 && !SN_PP_MERGE && !SN_PP_WPRE && !SN_PP_HSPREAD && !SN_PP_EARLYBAR && !SN_PP_DESIG && SN_PP_B128,
-                                      "SN_PP_AB: branch-free weight DMAs, default ping-pong options");
-                        static_assert(SN_TIMING == 0 || SN_TIMING >= 10, "SN_PP_AB: timing modes 10 (per tile), 11 (burst F: {wait for chunk 2p+1's operands, whole burst}), 12 ({load slot F, load slot M}), 13 ({burst M, its closing wait})");
-                        // ---- load slot F: 4 LDS reads, the whole next weight piece's DMAs
-                        const long long tL1 = SN_TIMING == 12 ? __builtin_readcyclecounter() : 0;
-                        if constexpr (!(SN_ABL & 32768)) load_x(I0{}, koA);
-                        // SN_PP_AB 2: the MX step's activation codes are read HERE, not in load slot M: that slot runs beside the partner's short MX
-                        // burst for one of the two groups (720 against 433 clocks, SN_TIMING 12 / 13), this one beside a burst with room to spare
-                        v8i x8[MF];
-                        v4i x8h[MF][2];
-                        constexpr int XE = SN_PP_AB >= 3 ? MF : (SN_PP_AB == 2 ? MF / 2 : 0);      // fragments read early (all of them: register spills in the NF = 7 kernels)
-                        if constexpr (SN_PP_AB >= 2) {
-                            const unsigned ks0 = xslab + C::XPLANE + (unsigned)(int)k2, ks1 = xslab + C::XPLANE + (unsigned)(int)(k2 >> 32);
-                            static_for<0, XE>([&](auto mc) {
-                                constexpr int m = decltype(mc)::value;
-                                lds_read128i<0>(x8h[m][0], (unsigned)xbase[m] + ks0);
-                                lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
-                            });
-                        }
-                        if constexpr (!(SN_ABL & 65536)) stage_w_part(w_off, wbi ^ 1, 0, WPW);
-                        lgkm_wait<0>();
-                        if constexpr (SN_PP_AB >= 2) {
-#pragma unroll
-                            for (int m = 0; m < XE; ++m) {
-                                asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
-                                x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
-                            }
-#pragma unroll
-                            for (int m = 0; m < XE; ++m) asm volatile("" : "+v"(x8[m]));
-                        }
-                        if constexpr (SN_TIMING == 12) { t_vm += __builtin_readcyclecounter() - tL1; ++n_piece; }
-                        wg_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                        const long long tC1 = SN_TIMING == 11 ? __builtin_readcyclecounter() : 0;
-                        {
-                            const unsigned kosB = xslab + (unsigned)koB;
-                            constexpr int RPG = 3;                         // operand reads of chunk 2p+1 per MFMA group: all MF + NF of them behind the first 4 groups
-                            static_assert(RPG * (NF - 2) >= MF + NF, "in-burst operand reads");
-                            static_for<0, NF>([&](auto nc) {
-                                constexpr int n = decltype(nc)::value;
-                                static_for<0, MF>([&](auto mc) {
-                                    constexpr int m = decltype(mc)::value;
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0c[n], xf[0][m], acc[m][n], 0, 0, 0);
-                                    if constexpr (SN_PP_RSPREAD) {        // one read behind every other MFMA (the next MFMA waits for the pipe anyway: a read that
-                                        constexpr int i = n * MF + m;      // stalls on a full LDS queue then delays nothing) instead of RPG behind each group of MF;
-                                        if constexpr (i % 2 == 1 && !(SN_ABL & 16384)) {        // (behind EVERY one: the operands of chunk 2p+1 turn live too early - spills)
-                                            constexpr int r = i / 2;
-                                            if constexpr (r < MF) lds_read128<0>(xf[1][r], (unsigned)xbase[r] + kosB);
-                                            else if constexpr (r < MF + NF) lds_read128<(NF + (r - MF)) * 1024>(wf[1][r - MF], wp);
-                                        }
-                                        __builtin_amdgcn_sched_barrier(0);
-                                    }
-                                });
-                                if constexpr (!SN_PP_RSPREAD && !(SN_ABL & 16384))
-                                static_for<0, RPG>([&](auto jc) {
-                                    constexpr int r = n * RPG + decltype(jc)::value;
-                                    if constexpr (r < MF) lds_read128<0>(xf[1][r], (unsigned)xbase[r] + kosB);
-                                    else if constexpr (r < MF + NF) lds_read128<(NF + (r - MF)) * 1024>(wf[1][r - MF], wp);
-                                });
-                                __builtin_amdgcn_sched_barrier(0);
-                            });
-                            if (has_B) {
-                                const long long tW = SN_TIMING == 11 ? __builtin_readcyclecounter() : 0;
-                                lgkm_wait<0>();
-                                if constexpr (SN_TIMING == 11) { t_vm += __builtin_readcyclecounter() - tW; ++n_piece; }
-                                static_for<0, NF>([&](auto nc) {
-                                    constexpr int n = decltype(nc)::value;
-                                    static_for<0, MF>([&](auto mc) {
-                                        constexpr int m = decltype(mc)::value;
-                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][n], xf[1][m], acc[m][n], 0, 0, 0);
-                                        if constexpr (SN_PP_RSPREAD && !(SN_ABL & 16384)) {
-                                            if constexpr (m == 0) lds_read128i<mxo + n * 2048>(wa4[n], wp);
-                                            if constexpr (m == 1) lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
-                                            if constexpr (m == 2 && n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
-                                            __builtin_amdgcn_sched_barrier(0);
-                                        }
-                                    });
-                                    if constexpr (!SN_PP_RSPREAD && !(SN_ABL & 16384)) {
-                                        if constexpr (n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
-                                        lds_read128i<mxo + n * 2048>(wa4[n], wp);
-                                        lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
-                                    }
-                                    __builtin_amdgcn_sched_barrier(0);
-                                });
-                            } else {
-                                load_mxw(I0{}, INF{});
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (SN_TIMING == 11) { if (has_B) t_bar += __builtin_readcyclecounter() - tC1; }
-                        wg_barrier();
-                        const long long tL2 = SN_TIMING == 12 ? __builtin_readcyclecounter() : 0;
-                        // ---- load slot M: the activation codes, next piece's tap offsets; DMA: the next slab's halo tile and tap table (first piece of a slab)
-                        {
-                            int koAn = 0, koBn = 0;
-                            long long k2n = 0;
-                            if constexpr (XE < MF && !(SN_ABL & 32768)) {
-                                const unsigned ks0 = xslab + C::XPLANE + (unsigned)(int)k2, ks1 = xslab + C::XPLANE + (unsigned)(int)(k2 >> 32);
-                                static_for<XE, MF>([&](auto mc) {
-                                    constexpr int m = decltype(mc)::value;
-                                    lds_read128i<0>(x8h[m][0], (unsigned)xbase[m] + ks0);
-                                    lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
-                                });
-                            }
-                            if (p + 1 < npiece) {
-                                lds_read32<0>(koAn, koff_a + (unsigned)(ch0 + 2) * 16);
-                                lds_read32<0>(koBn, koff_a + (unsigned)(ch0 + 3) * 16);
-                                lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
-                            }
-                            if (p == 0 && have_next && !(SN_ABL & (1 | 65536))) {
-                                hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
-                                if (wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
-                            }
-                            // the next weight piece (issued one load slot ago) has landed; this slab's halo DMAs, just issued, may still fly
-                            if (p + 1 < npiece && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
-                            else if (p + 1 < npiece && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
-                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            lgkm_wait<0>();
-                            v8i wa[NF];
-                            if constexpr (XE < MF) {
-#pragma unroll
-                                for (int m = XE; m < MF; ++m) {
-                                    asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
-                                    x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
-                                }
-                            }
-#pragma unroll
-                            for (int n = 0; n < NF; ++n) {
-                                const v2i_ b2 = __builtin_bit_cast(v2i_, wb2[n]);
-                                const v4i b4 = __builtin_shufflevector(b2, b2, 0, 1, -1, -1);
-                                wa[n] = __builtin_shufflevector(wa4[n], b4, 0, 1, 2, 3, 4, 5, -1, -1);
-                            }
-                            if (p + 1 < npiece) { koA = koAn; koB = koBn; k2 = k2n; }
-#pragma unroll
-                            for (int m = 0; m < MF; ++m) asm volatile("" : "+v"(x8[m]));
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (SN_TIMING == 12) t_bar += __builtin_readcyclecounter() - tL2;
-                            wg_barrier();
-                            __builtin_amdgcn_sched_barrier(0);
-                            const long long tC2 = SN_TIMING == 13 ? __builtin_readcyclecounter() : 0;
-                            const unsigned wpn = wbuf_a + (wbi ^ 1) * C::WBUF;          // the piece after this one
-                            static_for<0, NF>([&](auto nc) {
-                                constexpr int n = decltype(nc)::value;
-                                const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
-                                // the next piece's first weight fragments: all NF requested before the burst's last groups, so that the wait behind the
-                                // burst is free and the registers hold real data wherever the compiler may copy them at a loop edge
-                                static_for<0, MF>([&](auto mc) {
-                                    constexpr int m = decltype(mc)::value;
-                                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
-                                    if constexpr (SN_PP_RSPREAD && !(SN_ABL & 16384)) {
-                                        constexpr int r = n * MF + m;
-                                        if constexpr (r < NF) lds_read128<r * 1024>(wf0c[r], wpn);
-                                        __builtin_amdgcn_sched_barrier(0);
-                                    }
-                                });
-                                if constexpr (!SN_PP_RSPREAD && !(SN_ABL & 16384))
-                                static_for<0, 2>([&](auto jc) {
-                                    constexpr int r = n * 2 + decltype(jc)::value;
-                                    if constexpr (r < NF) lds_read128<r * 1024>(wf0c[r], wpn);
-                                });
-                                __builtin_amdgcn_sched_barrier(0);
-                            });
-                            const long long tC2w = SN_TIMING == 13 ? __builtin_readcyclecounter() : 0;
-                            lgkm_wait<0>();
-                            if constexpr (SN_TIMING == 13) { const long long te = __builtin_readcyclecounter(); t_vm += tC2w - tC2; t_bar += te - tC2w; ++n_piece; }
-                            wg_barrier();
-                        }
-                    } else {
-                    if constexpr (SN_PP_MERGE) {
-                        // ---- segment F: both f16 chunks of the piece, 2 * MF * NF MFMAs in one burst; DMA: the next weight piece; tap table of the next slab
+                    // ---- segment A: f16 chunk 2p; DMA: first part of the next weight piece; group 0 also writes the next slab's tap table
+                    PP_T(0);
+                    load_f16(I0{}, koA);
+                    if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WSPLIT);
+                    if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                    lgkm_wait<0>();
+                    PP_T(1);
+                    wg_barrier();
+                    PP_T(2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // (chunk 2p+1's fragments are requested even when the piece has no such chunk - in-bounds reads of the zero padding, never
+                    // used: a burst per case doubled the kernel's register pressure)
+                    if constexpr (PPWIN) compute_f16(I0{}, I1{}); else compute_f16(I0{}, I0{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_T(3);
+                    wg_barrier();
+                    PP_T(4);
+                    pp_account(false);
+                    // ---- segment B: f16 chunk 2p+1; DMA: the rest of the next weight piece
+                    if (has_B) {
                         PP_T(0);
-                        load_f16(I0{}, koA);
-                        if (has_B) load_f16(I1{}, koB);
-                        load_mxw(I0{}, INFB{});
-                        if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WPW);
-                        if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                        if constexpr (PPWIN) load_x(I1{}, koB); else load_f16(I1{}, koB);
+                        if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW);
                         lgkm_wait<0>();
                         PP_T(1);
                         wg_barrier();
                         PP_T(2);
                         __builtin_amdgcn_sched_barrier(0);
-                        compute_f16(I0{}, I0{}, !has_B);
-                        if (has_B) compute_f16(I1{}, I0{});
+                        if constexpr (PPWIN) compute_f16(I1{}, I2{}); else compute_f16(I1{}, I0{});
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
+                        PP_T(3);
+                        wg_barrier();
                         PP_T(4);
                         pp_account(false);
                     } else {
-                        // ---- segment A: f16 chunk 2p; DMA: first half of the next weight piece; group 0 also writes the next slab's tap table
-                        PP_T(0);
-                        if constexpr (SN_TIMING == 7 || SN_TIMING == 8) {
-                            if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WSPLIT);
-                            if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
-                            PP_TA();
-                        }
-                        load_f16(I0{}, koA);
-                        load_mxw(I0{}, INFA{});
-                        if constexpr (!(SN_TIMING == 7 || SN_TIMING == 8)) {
-                            if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WSPLIT);
-                            if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
-                        }
-                        lgkm_wait<0>();
-                        PP_T(1);
-                        wg_barrier();
-                        PP_T(2);
-                        __builtin_amdgcn_sched_barrier(0);
-                        // (chunk 2p+1's fragments are requested even when the piece has no such chunk - in-bounds reads of the zero padding, never
-                        // used: a burst per case doubled the kernel's register pressure)
-                        if constexpr (PPWIN) compute_f16(I0{}, I1{}); else compute_f16(I0{}, I0{});
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
-                        PP_T(4);
-                        pp_account(false);
-                        // ---- segment B: f16 chunk 2p+1; DMA: second half
-                        if (has_B) {
-                            PP_T(0);
-                            if constexpr (SN_TIMING == 7 || SN_TIMING == 8) { if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW); PP_TA(); }
-                            if constexpr (PPWIN) load_x(I1{}, koB); else load_f16(I1{}, koB);
-                            load_mxw(INFA{}, INFB{});
-                            if constexpr (!(SN_TIMING == 7 || SN_TIMING == 8)) { if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW); }
-                            halo_instalment();
-                            lgkm_wait<0>();
-                            PP_T(1);
-                            wg_barrier();
-                            PP_T(2);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (PPWIN) compute_f16(I1{}, I2{}); else compute_f16(I1{}, I0{});
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
-                            PP_T(4);
-                            pp_account(false);
-                        } else {
-                            if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW);
-                            halo_instalment();
-                        }
+                        if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW);
                     }
                     // ---- segment M: the MX step of the piece's 64 k; DMA: the next slab's halo tile (first piece of a slab); waits for the weights
                     {
                         PP_T(0);
-                        if constexpr (SN_TIMING == 7 || SN_TIMING == 8) {
-                            if (p == 0 && have_next)
-                                hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
-                            PP_TA();
-                        }
-                        v3i x6[MF][2];
-                        v4i x8h[MF][2];                                       // SN_PP_B128: whole slots (4 LDS cycles per read instead of 8; the pad dword is dropped below)
+                        v4i x8h[MF][2];                                       // whole code slots (4 LDS cycles per read instead of 8 for 96 bits; the pad dword is dropped below)
                         int koAn = 0, koBn = 0;
                         long long k2n = 0;
                         const unsigned ks0 = xslab + C::XPLANE + (unsigned)(int)k2, ks1 = xslab + C::XPLANE + (unsigned)(int)(k2 >> 32);
                         static_for<0, MF>([&](auto mc) {
                             constexpr int m = decltype(mc)::value;
-                            if constexpr (SN_PP_B128) {
-                                lds_read128i<0>(x8h[m][0], (unsigned)xbase[m] + ks0);
-                                lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
-                            } else {
-                                lds_read96i<0>(x6[m][0], (unsigned)xbase[m] + ks0);
-                                lds_read96i<0>(x6[m][1], (unsigned)xbase[m] + ks1);
-                            }
+                            lds_read128i<0>(x8h[m][0], (unsigned)xbase[m] + ks0);
+                            lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
                         });
-                        if constexpr (PPWIN && !SN_PP_MERGE) {
-                            if (!has_B) load_mxw(I0{}, INF{});              // (else: requested from inside chunk 2p+1's burst)
-                        } else
-                        if (!(SN_PP_WPRE && (SN_PP_MERGE || has_B))) {
-                            if constexpr (SN_PP_WPRE == 0 || SN_PP_MERGE) load_mxw(I0{}, INF{});
-                            else load_mxw(INFA{}, INF{});                  // (no chunk 2p+1 in this piece: its share of the fragments is read here)
-                        }
+                        if (!(PPWIN && has_B)) load_mxw();                     // (else: requested from inside chunk 2p+1's burst)
                         if (p + 1 < npiece) {
                             lds_read32<0>(koAn, koff_a + (unsigned)(ch0 + 2) * 16);
                             lds_read32<0>(koBn, koff_a + (unsigned)(ch0 + 3) * 16);
                             lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
                         }
-#ifndef SN_PP_NOHALO
-                        if (!SN_PP_HSPREAD && !(SN_TIMING == 7 || SN_TIMING == 8) && p == 0 && have_next && !(SN_ABL & 1))
-#else
-                        if (0)
-#endif
+                        if (p == 0 && have_next && !(SN_ABL & 1))
                             hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
                         long long pptv = 0;
                         if constexpr (SN_TIMING == 9) { lgkm_wait<0>(); pptv = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -1252,13 +956,8 @@ conv3d_f16_mfma(ConvArgs a)
                         v8i x8[MF], wa[NF];
 #pragma unroll
                         for (int m = 0; m < MF; ++m) {
-                            if constexpr (SN_PP_B128) {
-                                asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
-                                x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
-                            } else {
-                                asm volatile("" : "+v"(x6[m][0]), "+v"(x6[m][1]));
-                                x8[m] = __builtin_shufflevector(x6[m][0], x6[m][1], 0, 1, 2, 3, 4, 5, -1, -1);
-                            }
+                            asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
+                            x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
                         }
 #pragma unroll
                         for (int n = 0; n < NF; ++n) {
@@ -1267,7 +966,7 @@ conv3d_f16_mfma(ConvArgs a)
                             wa[n] = __builtin_shufflevector(wa4[n], b4, 0, 1, 2, 3, 4, 5, -1, -1);
                         }
                         if (p + 1 < npiece) { koA = koAn; koB = koBn; k2 = k2n; }
-                        // (pins the operand tuples - and the 3 register moves per activation fragment that forming them costs - in front of the barrier,
+                        // (pins the operand tuples - and the register moves per activation fragment that forming them costs - in front of the barrier,
                         // i.e. into the load segment: instruction selection otherwise sinks them to their first use, the head of the MFMA burst)
 #pragma unroll
                         for (int m = 0; m < MF; ++m) asm volatile("" : "+v"(x8[m]));
@@ -1279,7 +978,6 @@ conv3d_f16_mfma(ConvArgs a)
                         static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
                             const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
-                            if constexpr (SN_PP_EARLYBAR && n == NF - 1) { __builtin_amdgcn_sched_barrier(0); PP_T(3); wg_barrier(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                             for (int m = 0; m < ((SN_ABL & 8192) ? MF / 2 : MF); ++m)
                                 acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
@@ -1290,13 +988,12 @@ conv3d_f16_mfma(ConvArgs a)
                             }
                         });
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (!SN_PP_EARLYBAR) { PP_T(3); wg_barrier(); }
+                        PP_T(3);
+                        wg_barrier();
                         PP_T(4);
                         pp_account(true);
                     }
-                    }     // !SN_PP_AB
 #undef PP_T
-#undef PP_TA
                     wbi ^= 1;
                 } while (++p < npiece);
             } else {
@@ -1394,7 +1091,7 @@ conv3d_f16_mfma(ConvArgs a)
                     }
                 };
                 if constexpr (!SN_DMA_LATE) { if (!DEFER || p == 0) issue_dmas(p, ch0, wbi); }
-                if constexpr (SN_TIMING >= 7) { t_dma = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                if constexpr (SN_TIMING == 7 || SN_TIMING == 8) { t_dma = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                 static_for<0, C::PCH>([&](auto ccc) {
                     constexpr int cc = decltype(ccc)::value;
                     const int ch = ch0 + cc;
@@ -1628,7 +1325,7 @@ conv3d_f16_mfma(ConvArgs a)
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if constexpr (SN_TIMING) { tq1 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                     wg_barrier();                             // ... for every wave; this piece's buffers are free again
-                    if constexpr (SN_TIMING) {
+                    if constexpr (SN_TIMING >= 1 && SN_TIMING <= 8) {      // (9, 10: modes of the ping-pong loops / per tile)
                         const long long tq2 = __builtin_readcyclecounter();
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         if constexpr (SN_TIMING >= 7) {       // 7 / 8: [1] += piece start -> weight DMAs issued (and the first fragments landed), [2] += the rest of chunk 0

@@ -3,11 +3,12 @@
     hipcc ... -DSN_TIMING=1 (conv3d_mfma.h) -> SURFACENET_HIP_LIB=<that .so> python tools/wave_timing.py
 Every wave accumulates shader-clock totals (whole kernel, the vmcnt wait in front of each per-piece barrier, the barrier itself); the
 script runs the headline batch a few times and prints, per layer, the share of wave time spent in the two waits.
--DSN_TIMING=3..8 (f16m8 kernels, i.e. merge_conv_a/b) put SEGMENT times of a weight piece into the two wait columns instead, odd values for
-waves >= NW/2 (the prioritised half), even for the others: 3/4 = piece start -> MX step done | MX step done -> end of chunk 1;
-5/6 = piece start -> end of chunk 0 | the MX step; 7/8 = piece start -> DMAs issued and first fragments landed | the rest of chunk 0.
-The printed "wait/piece" figures then average over ALL waves and pieces: multiply by 2 / (share of pieces with p > 0 in a slab, 3/4 for the
-merge layers) to get clocks per piece of the measured half. These builds disable the deferred barrier."""
+-DSN_TIMING=1..6, 9 (ping-pong f16m8 kernels, i.e. merge_conv_a/b): the two columns hold SEGMENT times instead - 1: {load, wait at the barrier},
+2: {MFMA burst, wait}, 3 / 4: the same for the MX segments only, 5 / 6: for the f16 segments only, 9: {the MX segments' vmcnt wait, everything in
+front of it}; "pieces" then counts segments. -DSN_TIMING=10 (every conv kernel): per TILE {store epilogue, K loop}. 3..8 on the pipelined loop
+(kernels the ping-pong loops do not cover): sub-piece times, see conv3d_mfma.h. A stamp costs ~40 clocks and its lgkmcnt(0) also waits for the
+wave's in-flight prefetch reads: instrumented builds run 10-25 % slower and shift time between neighbouring columns.
+--simil: the similarityNet's layers instead of the SurfaceNet's."""
 import ctypes
 import os
 import sys
