@@ -176,6 +176,7 @@ struct ConvArgs {
                           // epilogue store bursts do not hit HBM at the same instant (0 = off)
     int nslab;
     unsigned char slab_c8[kMaxSlab];  // 8-channel groups per slab
+    int bridge;           // 2-D f16x3 kernels, two-group slabs (18 (tap, group) units = 4.5 K-chunks): see write_koff_part
 };
 
 enum { EPI_STORE = 0, EPI_FINAL = 1, EPI_POOL2D = 2, EPI_SIDEPOOL = 3 };   // POOL2D (2-D nets): store epilogue fused with the 2x2 max-pool that follows;
@@ -508,20 +509,41 @@ conv3d_f16_mfma(ConvArgs a)
     // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n; raw s_barrier (a __syncthreads() would make hipcc drain
     // vmcnt(0) because LDS-DMAs are pending, defeating the counted wait)
     auto wg_barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
-    auto write_koff_part = [&](int c8n, int kb, int t0, int nt) {
-        const int G = C::NTAP * c8n, nchunk = (G + 3) >> 2;
+    // BRIDGE (2-D f16x3 kernels whose slabs hold two channel groups: 9 taps x 2 = 18 (tap, group) units = 4.5 K-chunks): instead of padding
+    // every slab to 5 chunks, the 5th chunk of an EVEN slab takes its two left-over units and the FIRST two units of the next slab, which then
+    // starts at its unit 2 and is exactly 4 chunks - 9 chunks per slab pair instead of 10, i.e. 10 % fewer MFMAs and LDS reads. The next
+    // slab's halo tile sits in the OTHER halo buffer and has landed by then (its DMAs are issued in the slab's first piece, the wait of the
+    // second piece is a vmcnt(0)): the two bridge entries of the tap table simply carry that buffer's distance. pack_conv_host lays the
+    // weights out in the same unit order and decides whether a layer qualifies (a.bridge).
+    constexpr bool BRIDGE_OK = (K2D != 0 && SPLIT == 1 && KS == 3);
+    const bool bridge = BRIDGE_OK && a.bridge != 0;
+    auto chunks_of = [&](int c8n, int slab) {
+        const int G = C::NTAP * c8n;
+        return bridge ? ((G + ((slab & 1) ? -2 : 2)) >> 2) : ((G + 3) >> 2);
+    };
+    // K-chunks the weight STREAM holds for a slab (f16m8 pads every slab to whole pieces)
+    auto wchunks_of = [&](int c8n, int slab) { return SPLIT == 2 ? (((C::NTAP * c8n + 7) >> 3) << 1) : chunks_of(c8n, slab); };
+    // tap table of slab `slab` (c8n groups) into table buffer kb (= the halo buffer that holds the slab): entry g = LDS byte offset of
+    // (tap, group) unit g's 16-byte slot relative to a voxel's own slot
+    auto write_koff_part = [&](int c8n, int kb, int slab, int t0, int nt) {
+        const int G = C::NTAP * c8n, nchunk = chunks_of(c8n, slab);
         int *k = kbuf + kb * C::KOFF_N;
         for (int g = t0; g < (nchunk + 4) * 4; g += nt) {
-            int o = 0;
-            if (g < G) {
-                const int tap = g / c8n, c8 = g - tap * c8n;
+            int o = 0, u = g, far = 0;
+            bool valid = g < G;
+            if (bridge) {
+                if (slab & 1) { u = g + 2; valid = u < G; }
+                else if (g >= G && g < G + 2) { u = g - G; valid = true; far = (1 - 2 * kb) * C::XBUF; }
+            }
+            if (valid) {
+                const int tap = u / c8n, c8 = u - tap * c8n;
                 const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
-                o = ((dx * DIL * C::HY + dy * DIL) * C::HZ + dz * DIL) * C::VS + c8 * 16;
+                o = ((dx * DIL * C::HY + dy * DIL) * C::HZ + dz * DIL) * C::VS + c8 * 16 + far;
             }
             k[g] = o;
         }
     };
-    auto write_koff = [&](int c8n, int kb) { write_koff_part(c8n, kb, tid, C::NT); };
+    auto write_koff = [&](int c8n, int kb, int slab) { write_koff_part(c8n, kb, slab, tid, C::NT); };
     // LDS-DMA of `nch` K-chunks of packed weights starting at byte offset `off` of this split's stream
     auto stage_w = [&](size_t off, int nch, int wbi) {
         const int cnt = nch * NF * NPL;
@@ -529,9 +551,6 @@ conv3d_f16_mfma(ConvArgs a)
         char *dst = wbuf + wbi * C::WBUF;
         for (int i = wave; i < cnt; i += C::NW) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
     };
-    auto chunks_of = [&](int c8n) { return (C::NTAP * c8n + 3) >> 2; };
-    // K-chunks the weight STREAM holds for a slab (f16m8 pads every slab to whole pieces)
-    auto wchunks_of = [&](int c8n) { return SPLIT == 2 ? (((C::NTAP * c8n + 7) >> 3) << 1) : ((C::NTAP * c8n + 3) >> 2); };
 
     // Position of voxel fragment m's lane inside the workgroup's output tile. Default: wave w owns x-slices [w*XS, (w+1)*XS), a fragment is
     // 2 y-rows x 8 z. PMAP (EPI_SIDEPOOL): wave w owns x in {2(w&3), 2(w&3)+1} x 4 y-rows, so that every 2x2x2 pooling cell lies inside ONE
@@ -583,8 +602,8 @@ conv3d_f16_mfma(ConvArgs a)
             tile_halo_consts(x0, y0, z0, keep, toff);
             stage_halo_buf(K2D ? x0 : b, keep, toff, 0, c8n, 0);
         } else stage_halo(tile, 0, c8n, 0, 0, HT);
-        write_koff(c8n, 0);
-        const int nch = wchunks_of(c8n);
+        write_koff(c8n, 0, 0);
+        const int nch = wchunks_of(c8n, 0);
         stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         wg_barrier();
@@ -636,7 +655,7 @@ conv3d_f16_mfma(ConvArgs a)
         const long long t_tile0 = SN_TIMING == 10 ? __builtin_readcyclecounter() : 0;     // 10: per tile {epilogue, K loop}
         for (int slab = 0; slab < a.nslab; ++slab) {
             const int c8n = a.slab_c8[slab];
-            const int nchunk = chunks_of(c8n);
+            const int nchunk = chunks_of(c8n, slab);
             const int npiece = (nchunk + C::PCH - 1) / C::PCH;
             // what comes after this slab: next slab of this tile, or slab 0 of this workgroup's next tile
             const bool last_slab = slab + 1 == a.nslab;
@@ -645,9 +664,9 @@ conv3d_f16_mfma(ConvArgs a)
             const int nslab_i = last_slab ? 0 : slab + 1;
             const int nc8n = a.slab_c8[nslab_i];
             const int nc0 = last_slab ? 0 : c0 + c8n;
-            const int wchunk = wchunks_of(c8n);
+            const int wchunk = wchunks_of(c8n, slab);
             const size_t nwoff = last_slab ? 0 : woff + (size_t)wchunk * NF * C::FRAG;
-            if constexpr (!PP) { if (have_next) write_koff(nc8n, xb ^ 1); }
+            if constexpr (!PP) { if (have_next) write_koff(nc8n, xb ^ 1, nslab_i); }
             // the next halo tile is fetched in npiece-1 instalments, each issued right after a weight piece so that a
             // counted vmcnt can wait for the weights while the newest halo DMAs stay in flight
             // Instalment size HQ is a compile-time constant (sized for a full slab) so that the wait in front of the barrier is a
@@ -685,7 +704,7 @@ conv3d_f16_mfma(ConvArgs a)
                     const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
                     int w_nch = C::PCH;
                     if (p + 1 < npiece) { const int rem = wchunk - (ch0 + C::PCH); if (rem < C::PCH) w_nch = rem; }
-                    else { const int nch = wchunks_of(nc8n); if (nch < C::PCH) w_nch = nch; }
+                    else { const int nch = wchunks_of(nc8n, nslab_i); if (nch < C::PCH) w_nch = nch; }
                     int hnow = 0;
                     static_for<0, NSEGMAX>([&](auto scc) {
                         constexpr int sc = decltype(scc)::value;
@@ -718,7 +737,7 @@ conv3d_f16_mfma(ConvArgs a)
                                     const bool real = w_next;
                                     const char *src = wsrc0 + (real ? w_off : 0);
                                     char *dst = wbuf + (wbi ^ 1) * C::WBUF;
-                                    const int nch0 = wchunks_of(a.slab_c8[0]);
+                                    const int nch0 = wchunks_of(a.slab_c8[0], 0);
                                     const int cnt = (real ? w_nch : (nch0 < C::PCH ? nch0 : C::PCH)) * NF * NPL;
                                     constexpr int WPWX = (C::PCH * NF * NPL + C::NW - 1) / C::NW;
                                     static_for<0, WPWX>([&](auto kc) {
@@ -733,7 +752,7 @@ conv3d_f16_mfma(ConvArgs a)
                                     const int cnt = w_nch * NF * NPL;
                                     for (int i = wave; i < cnt; i += C::NW) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
                                 }
-                                if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                                if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, nslab_i, tid, C::NT / 2);
                             }
                             // the next slab's halo tile: second segment of the slab's first piece (first segment if the piece has only one)
                             if (p == 0 && have_next && !(SN_ABL & 1) && sc == (nseg >= 2 ? 1 : 0))
@@ -888,7 +907,7 @@ conv3d_f16_mfma(ConvArgs a)
                     PP_T(0);
                     load_f16(I0{}, koA);
                     if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WSPLIT);
-                    if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, tid, C::NT / 2);
+                    if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, nslab_i, tid, C::NT / 2);
                     lgkm_wait<0>();
                     PP_T(1);
                     wg_barrier();
@@ -1077,7 +1096,7 @@ conv3d_f16_mfma(ConvArgs a)
                         const int rem = wchunk - (ch0 + C::PCH);
                         stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
                     } else if (have_next) {
-                        const int nch = wchunks_of(nc8n);
+                        const int nch = wchunks_of(nc8n, nslab_i);
                         stage_w(nwoff, nch < C::PCH ? nch : C::PCH, wbi ^ 1);
                     }
                     if constexpr (BUFH) {

@@ -121,25 +121,40 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
         return (o < L.cout && ci < L.cin) ? W[((size_t)o * L.cin + ci) * ntap + tap] : 0.f;
     };
     h.clear();
+    // bridge chunks (conv3d_mfma.h, write_koff_part): asked for by the caller (L.bridge), granted to 2-D f16x3 layers whose slabs all hold two
+    // channel groups (18 (tap, group) units = 4.5 K-chunks) and come in pairs: the 5th chunk of an even slab = its units 16, 17 + units 0, 1 of
+    // the next slab, which starts at its unit 2
+    {
+        bool ok = L.bridge && L.k2d != 0 && split == 1 && L.ks == 3 && cs8max == 2 && L.slab_c8.size() % 2 == 0;
+        for (unsigned char c8n : L.slab_c8) ok = ok && c8n == 2;
+        L.bridge = ok ? 1 : 0;
+    }
     if (split != 2) {
+        auto slab_chunks = [&](int si, int c8n) { const int G = ntap * c8n; return L.bridge ? (G + ((si & 1) ? -2 : 2)) / 4 : (G + 3) / 4; };
         long long chunks = 0;
-        for (unsigned char c8n : L.slab_c8) chunks += (ntap * c8n + 3) / 4;
+        for (size_t si = 0; si < L.slab_c8.size(); ++si) chunks += slab_chunks((int)si, L.slab_c8[si]);
         L.wsplit_stride = chunks * nf * 512 * npl;
         h.assign((size_t)L.wsplit_stride * nsplit, (_Float16)0.f);
         for (int ns = 0; ns < nsplit; ++ns) {
             _Float16 *dst = h.data() + (size_t)ns * L.wsplit_stride;
             int c8_0 = 0;
-            for (unsigned char c8n : L.slab_c8) {
-                const int G = ntap * c8n, nchunk = (G + 3) / 4;
+            for (size_t si = 0; si < L.slab_c8.size(); ++si) {
+                const int c8n = L.slab_c8[si];
+                const int G = ntap * c8n, nchunk = slab_chunks((int)si, c8n);
                 for (int ch = 0; ch < nchunk; ++ch)
                     for (int f = 0; f < nf; ++f)
                         for (int lane = 0; lane < 64; ++lane) {
                             const int o = (ns * nf + f) * 16 + (lane & 15);
                             const int g = 4 * ch + (lane >> 4);
                             _Float16 *d8 = dst + (((size_t)ch * nf + f) * npl * 64 + lane) * 8;
-                            if (g >= G) continue;
+                            int u = g, cb = c8_0, cn = c8n;                 // unit u of the slab whose first group is cb
+                            if (L.bridge) {
+                                if (si & 1) u = g + 2;
+                                else if (g >= G) { u = g - G; cb = c8_0 + c8n; cn = L.slab_c8[si + 1]; }
+                            }
+                            if (u >= ntap * cn) continue;
                             for (int j = 0; j < 8; ++j) {
-                                const float w = wat(o, c8_0 + g % c8n, j, g / c8n);
+                                const float w = wat(o, cb + u % cn, j, u / cn);
                                 const _Float16 hi = (_Float16)w;
                                 d8[j] = hi;
                                 if (split == 1) d8[512 + j] = (_Float16)(w - (float)hi);
@@ -1192,6 +1207,7 @@ SN_API int sn_debug_pack_host(int cin, int cout, int ks, int dil, int k2d, int n
     if (!W || !beta || !gamma || !mean || !inv_std || !out) return fail(SN_ERR_ARG, "null argument");
     PackedConv L;
     L.name = "debug"; L.cin = cin; L.cout = cout; L.ks = ks; L.dil = dil; L.k2d = k2d;
+    L.bridge = k2d != 0;                  // as sn_simil.hip asks for them (granted to the f16x3 two-group-slab layers only)
     std::vector<_Float16> h;
     std::vector<float> sc, sh;
     const int rc = pack_conv_host(L, W, beta, gamma, mean, inv_std, nf, nsplit, cs8max, split, nullptr, nullptr, h, sc, sh);

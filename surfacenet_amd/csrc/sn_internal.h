@@ -54,6 +54,7 @@ struct PackedConv {
     int cin_p = 0;             // input channels padded to 8
     int nf = 0, nsplit = 1;    // 16-channel fragments per workgroup, workgroup columns
     int cs8max = 4, split = 0, k2d = 0;   // k2d: ks x ks taps over (y,z) only (2-D nets)
+    int bridge = 0;            // in: bridge chunks wanted; out of pack_conv: granted (sn_api.hip pack_conv_host, conv3d_mfma.h write_koff_part)
     std::vector<unsigned char> slab_c8;
     long long wsplit_stride = 0;   // halfs
     _Float16 *wpack = nullptr;     // device
@@ -269,6 +270,9 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
         a.status_bit = bit < 31 ? (1u << bit) : (1u << 31);
     }
     a.nslab = (int)L.slab_c8.size();
+    a.bridge = L.bridge;
+    if (L.bridge && !(K2D != 0 && SPLIT == 1 && KS == 3 && NW == 8 && PCH >= 2 && CS8 == 2))
+        return fail(SN_ERR_STATE, "%s: packed with bridge chunks, launched on a kernel without them", L.name.c_str());
     for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
     const double vox = (double)B * DX * D * D;
     const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : (EPI == EPI_SIDEPOOL ? 16 + L.cout / 8.0 : L.cout)));
