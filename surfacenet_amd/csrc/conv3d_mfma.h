@@ -176,7 +176,7 @@ struct ConvArgs {
                           // epilogue store bursts do not hit HBM at the same instant (0 = off)
     int nslab;
     unsigned char slab_c8[kMaxSlab];  // 8-channel groups per slab
-    int bridge;           // 2-D f16x3 kernels, two-group slabs (18 (tap, group) units = 4.5 K-chunks): see write_koff_part
+    int bridge;           // f16x3 kernels on the ping-pong loop: a slab's last K-chunk is filled up with the next slab's first units (write_koff_part)
 };
 
 enum { EPI_STORE = 0, EPI_FINAL = 1, EPI_POOL2D = 2, EPI_SIDEPOOL = 3 };   // POOL2D (2-D nets): store epilogue fused with the 2x2 max-pool that follows;
@@ -330,6 +330,11 @@ struct ConvCfg {
     // two waves per SIMD (8-wave workgroup or two 4-wave workgroups per CU): keep <= 256 registers per lane
     static constexpr int MIN_WAVES_PER_SIMD = (NW == 8 || WG_PER_CU == 2) ? 2 : 1;
 };
+
+// Does this configuration run the f16 / f16x3 ping-pong loop with bridge chunks (kernel: PPX, BRIDGE_OK)? - the launcher refuses a layer packed
+// with bridge chunks on any other kernel
+template <int KS, int SPLIT, int NW, int PCH, int NF, int K2D>
+constexpr bool sn_conv_has_bridge() { return SN_PPX && SN_PPX_SEGC == 1 && SPLIT == 1 && NW == 8 && KS == 3 && PCH >= 2 && NF >= SN_PPX_MINNF; }
 
 // OSPLIT: storage format of the OUTPUT tensor (defaults to SPLIT): lets an f16x3 layer feed an f16m8 layer.
 template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_, int K2D = 0, int OSPLIT_ = -1>
@@ -509,33 +514,39 @@ conv3d_f16_mfma(ConvArgs a)
     // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n; raw s_barrier (a __syncthreads() would make hipcc drain
     // vmcnt(0) because LDS-DMAs are pending, defeating the counted wait)
     auto wg_barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
-    // BRIDGE (2-D f16x3 kernels whose slabs hold two channel groups: 9 taps x 2 = 18 (tap, group) units = 4.5 K-chunks): instead of padding
-    // every slab to 5 chunks, the 5th chunk of an EVEN slab takes its two left-over units and the FIRST two units of the next slab, which then
-    // starts at its unit 2 and is exactly 4 chunks - 9 chunks per slab pair instead of 10, i.e. 10 % fewer MFMAs and LDS reads. The next
-    // slab's halo tile sits in the OTHER halo buffer and has landed by then (its DMAs are issued in the slab's first piece, the wait of the
-    // second piece is a vmcnt(0)): the two bridge entries of the tap table simply carry that buffer's distance. pack_conv_host lays the
-    // weights out in the same unit order and decides whether a layer qualifies (a.bridge).
-    constexpr bool BRIDGE_OK = (K2D != 0 && SPLIT == 1 && KS == 3);
+    // BRIDGE chunks (f16x3 kernels on the ping-pong loop; all slabs of a layer hold the same number of channel groups): a slab's NTAP * c8n
+    // (tap, group) units are not a multiple of the 4 a K-chunk holds - 27 = 6.75 chunks in the 3-D nets, 18 = 4.5 in the similarityNet - and
+    // used to be padded with zero weights slab by slab. Now the last chunk of a slab is filled up with the FIRST units of the next slab of the
+    // tile (b of them), which then starts at its unit o = b: 27 chunks per four 3-D slabs instead of 28, 9 per two 2-D slabs instead of 10.
+    // The next slab's halo tile sits in the OTHER halo buffer and has landed by then (its DMAs are issued in the slab's first piece; the
+    // segment in front of the bridge chunk waits vmcnt(0) before its barrier): the bridge entries of the tap table simply carry that buffer's
+    // distance. pack_conv_host lays the weights out in the same unit order and decides whether a layer qualifies (a.bridge).
+    constexpr bool BRIDGE_OK = PPX && SPLIT == 1 && SN_PPX_SEGC == 1;
     const bool bridge = BRIDGE_OK && a.bridge != 0;
-    auto chunks_of = [&](int c8n, int slab) {
-        const int G = C::NTAP * c8n;
-        return bridge ? ((G + ((slab & 1) ? -2 : 2)) >> 2) : ((G + 3) >> 2);
+    // units of slab `slab` in its chunks: GU - o of its own (o: taken by the slab before) + b of the next slab's
+    auto slab_units = [&](int c8n, int slab, int &o, int &b) {
+        const int GU = C::NTAP * c8n;
+        o = 0; b = 0;
+        if (bridge) {
+            o = (slab * ((4 - (GU & 3)) & 3)) & 3;
+            b = (slab + 1 == a.nslab) ? 0 : ((4 - ((GU - o) & 3)) & 3);
+        }
+        return GU - o + b;
     };
+    auto chunks_of = [&](int c8n, int slab) { int o, b; return (slab_units(c8n, slab, o, b) + 3) >> 2; };
     // K-chunks the weight STREAM holds for a slab (f16m8 pads every slab to whole pieces)
     auto wchunks_of = [&](int c8n, int slab) { return SPLIT == 2 ? (((C::NTAP * c8n + 7) >> 3) << 1) : chunks_of(c8n, slab); };
     // tap table of slab `slab` (c8n groups) into table buffer kb (= the halo buffer that holds the slab): entry g = LDS byte offset of
     // (tap, group) unit g's 16-byte slot relative to a voxel's own slot
     auto write_koff_part = [&](int c8n, int kb, int slab, int t0, int nt) {
-        const int G = C::NTAP * c8n, nchunk = chunks_of(c8n, slab);
+        int uo, ub;
+        const int own = slab_units(c8n, slab, uo, ub) - ub, nchunk = (own + ub + 3) >> 2;
         int *k = kbuf + kb * C::KOFF_N;
         for (int g = t0; g < (nchunk + 4) * 4; g += nt) {
-            int o = 0, u = g, far = 0;
-            bool valid = g < G;
-            if (bridge) {
-                if (slab & 1) { u = g + 2; valid = u < G; }
-                else if (g >= G && g < G + 2) { u = g - G; valid = true; far = (1 - 2 * kb) * C::XBUF; }
-            }
-            if (valid) {
+            int o = 0;
+            if (g < own + ub) {
+                const int u = g < own ? g + uo : g - own;                       // unit of this slab | bridge: of the next one, in the other halo buffer
+                const int far = g < own ? 0 : (1 - 2 * kb) * C::XBUF;
                 const int tap = u / c8n, c8 = u - tap * c8n;
                 const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
                 o = ((dx * DIL * C::HY + dy * DIL) * C::HZ + dz * DIL) * C::VS + c8 * 16 + far;
@@ -691,6 +702,8 @@ conv3d_f16_mfma(ConvArgs a)
                 const unsigned xslab = xbuf_a + xb * C::XBUF;
                 constexpr int NPLM = C::NPLM;
                 int ko[SEGC], ko_n[SEGC];
+                int bridge_o = 0, bridge_b = 0;                     // bridge chunks (write_koff_part): units this slab's last chunk takes from the next slab
+                if (bridge) slab_units(c8n, slab, bridge_o, bridge_b);
                 static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_read32<j * 16>(ko[j], koff_a); ko_n[j] = 0; });
                 lgkm_wait<0>();
                 int p = 0;
@@ -757,12 +770,14 @@ conv3d_f16_mfma(ConvArgs a)
                             // the next slab's halo tile: second segment of the slab's first piece (first segment if the piece has only one)
                             if (p == 0 && have_next && !(SN_ABL & 1) && sc == (nseg >= 2 ? 1 : 0))
                                 hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                            // (bridge chunk next: it reads the NEXT slab's halo tile - everything this wave has in flight must have landed before the barrier)
+                            const bool pre_bridge = bridge_b > 0 && ch0 + sc == nchunk - 2;
                             if (sc == nseg - 1) {
                                 // the next weight piece has landed; halo DMAs issued in THIS load segment may still fly unless the slab ends here
-                                if (p + 1 < npiece && sc == 1 && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
-                                else if (p + 1 < npiece && sc == 1 && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
+                                if (!pre_bridge && p + 1 < npiece && sc == 1 && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
+                                else if (!pre_bridge && p + 1 < npiece && sc == 1 && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
                                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            }
+                            } else if (pre_bridge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             lgkm_wait<0>();
                             static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; ko[j] = ko_n[j]; });
                             wg_barrier();

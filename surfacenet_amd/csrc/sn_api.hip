@@ -121,40 +121,45 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
         return (o < L.cout && ci < L.cin) ? W[((size_t)o * L.cin + ci) * ntap + tap] : 0.f;
     };
     h.clear();
-    // bridge chunks (conv3d_mfma.h, write_koff_part): asked for by the caller (L.bridge), granted to 2-D f16x3 layers whose slabs all hold two
-    // channel groups (18 (tap, group) units = 4.5 K-chunks) and come in pairs: the 5th chunk of an even slab = its units 16, 17 + units 0, 1 of
-    // the next slab, which starts at its unit 2
+    // bridge chunks (conv3d_mfma.h, write_koff_part): asked for by the caller (L.bridge), granted to f16x3 3x3(x3) layers whose slabs all hold the
+    // same number of channel groups and whose units per slab are not a multiple of 4: the last K-chunk of a slab is filled up with the first
+    // b units of the next slab, which starts at its unit o = b
     {
-        bool ok = L.bridge && L.k2d != 0 && split == 1 && L.ks == 3 && cs8max == 2 && L.slab_c8.size() % 2 == 0;
-        for (unsigned char c8n : L.slab_c8) ok = ok && c8n == 2;
+        bool ok = L.bridge && split == 1 && L.ks == 3 && L.slab_c8.size() >= 2 && (ntap * cs8max) % 4 != 0;
+        for (unsigned char c8n : L.slab_c8) ok = ok && c8n == cs8max;
         L.bridge = ok ? 1 : 0;
     }
     if (split != 2) {
-        auto slab_chunks = [&](int si, int c8n) { const int G = ntap * c8n; return L.bridge ? (G + ((si & 1) ? -2 : 2)) / 4 : (G + 3) / 4; };
+        const int nslab = (int)L.slab_c8.size();
+        // units of slab si in its chunks: GU - o of its own + b of the next slab's (the kernel's slab_units)
+        auto slab_units = [&](int si, int c8n, int &o, int &b) {
+            const int GU = ntap * c8n;
+            o = 0; b = 0;
+            if (L.bridge) { o = (si * ((4 - (GU & 3)) & 3)) & 3; b = (si + 1 == nslab) ? 0 : ((4 - ((GU - o) & 3)) & 3); }
+            return GU - o + b;
+        };
         long long chunks = 0;
-        for (size_t si = 0; si < L.slab_c8.size(); ++si) chunks += slab_chunks((int)si, L.slab_c8[si]);
+        for (int si = 0; si < nslab; ++si) { int o, b; chunks += (slab_units(si, L.slab_c8[si], o, b) + 3) / 4; }
         L.wsplit_stride = chunks * nf * 512 * npl;
         h.assign((size_t)L.wsplit_stride * nsplit, (_Float16)0.f);
         for (int ns = 0; ns < nsplit; ++ns) {
             _Float16 *dst = h.data() + (size_t)ns * L.wsplit_stride;
             int c8_0 = 0;
-            for (size_t si = 0; si < L.slab_c8.size(); ++si) {
+            for (int si = 0; si < nslab; ++si) {
                 const int c8n = L.slab_c8[si];
-                const int G = ntap * c8n, nchunk = slab_chunks((int)si, c8n);
+                int uo, ub;
+                const int own = slab_units(si, c8n, uo, ub) - ub, nchunk = (own + ub + 3) / 4;
                 for (int ch = 0; ch < nchunk; ++ch)
                     for (int f = 0; f < nf; ++f)
                         for (int lane = 0; lane < 64; ++lane) {
                             const int o = (ns * nf + f) * 16 + (lane & 15);
                             const int g = 4 * ch + (lane >> 4);
                             _Float16 *d8 = dst + (((size_t)ch * nf + f) * npl * 64 + lane) * 8;
-                            int u = g, cb = c8_0, cn = c8n;                 // unit u of the slab whose first group is cb
-                            if (L.bridge) {
-                                if (si & 1) u = g + 2;
-                                else if (g >= G) { u = g - G; cb = c8_0 + c8n; cn = L.slab_c8[si + 1]; }
-                            }
-                            if (u >= ntap * cn) continue;
+                            if (g >= own + ub) continue;                                    // zero padding (a tile's last slab)
+                            const int u = g < own ? g + uo : g - own;                       // unit of this slab | bridge: of the next one
+                            const int cb = g < own ? c8_0 : c8_0 + c8n;
                             for (int j = 0; j < 8; ++j) {
-                                const float w = wat(o, cb + u % cn, j, u / cn);
+                                const float w = wat(o, cb + u % c8n, j, u / c8n);
                                 const _Float16 hi = (_Float16)w;
                                 d8[j] = hi;
                                 if (split == 1) d8[512 + j] = (_Float16)(w - (float)hi);
@@ -711,6 +716,8 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
                 const float m = std::max(std::fabs(gamma[o]), std::fabs(beta[o]));
                 if (m > 0.f && std::isfinite(m)) oe[o] = std::max(-60, std::min(60, -std::ilogb(m)));
             }
+        static const bool no_bridge = getenv("SN_NO_BRIDGE") != nullptr;               // (A/B switch)
+        L.bridge = (SN_PPX && lsplit == 1 && k == 3 && !no_bridge) ? 1 : 0;             // f16x3 3x3x3 layers: 27 chunks per four slabs instead of 28 (pack_conv_host decides)
         if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit, in_exp, oe.data())) != SN_OK) return rc;
         c->conv[L.name] = L;
     }
@@ -1207,7 +1214,7 @@ SN_API int sn_debug_pack_host(int cin, int cout, int ks, int dil, int k2d, int n
     if (!W || !beta || !gamma || !mean || !inv_std || !out) return fail(SN_ERR_ARG, "null argument");
     PackedConv L;
     L.name = "debug"; L.cin = cin; L.cout = cout; L.ks = ks; L.dil = dil; L.k2d = k2d;
-    L.bridge = k2d != 0;                  // as sn_simil.hip asks for them (granted to the f16x3 two-group-slab layers only)
+    L.bridge = 1;                         // as the nets ask for them (granted to the f16x3 3x3 layers with uniform slabs only)
     std::vector<_Float16> h;
     std::vector<float> sc, sh;
     const int rc = pack_conv_host(L, W, beta, gamma, mean, inv_std, nf, nsplit, cs8max, split, nullptr, nullptr, h, sc, sh);

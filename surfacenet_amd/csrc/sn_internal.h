@@ -271,7 +271,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     }
     a.nslab = (int)L.slab_c8.size();
     a.bridge = L.bridge;
-    if (L.bridge && !(K2D != 0 && SPLIT == 1 && KS == 3 && NW == 8 && PCH >= 2 && CS8 == 2))
+    if (L.bridge && !sn::sn_conv_has_bridge<KS, SPLIT, NW, PCH, NF, K2D>())
         return fail(SN_ERR_STATE, "%s: packed with bridge chunks, launched on a kernel without them", L.name.c_str());
     for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
     const double vox = (double)B * DX * D * D;
