@@ -317,7 +317,7 @@ struct ConvCfg {
     static_assert(SPLIT != 2 || PCH_ == 2, "f16m8: a weight piece is 2 K-chunks + one MX step");
     static constexpr int WBUF = PCH * NF * FRAG;
     static constexpr int NTAP = (K2D ? 1 : KS) * KS * KS;
-    static constexpr int KOFF_N = NTAP * CS8MAX + 20;      // + look-ahead padding (2 chunks; f16m8: one 8-group piece)
+    static constexpr int KOFF_N = NTAP * CS8MAX + 24;      // + look-ahead padding (2 chunks; f16m8: one 8-group piece; bridged slabs: up to 7 units of the next slab)
     static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
     static constexpr int XPLANE = NSEG * 1024;
     static constexpr int XBUF = XPLANE * NPL;
@@ -334,7 +334,11 @@ struct ConvCfg {
 // Does this configuration run the f16 / f16x3 ping-pong loop with bridge chunks (kernel: PPX, BRIDGE_OK)? - the launcher refuses a layer packed
 // with bridge chunks on any other kernel
 template <int KS, int SPLIT, int NW, int PCH, int NF, int K2D>
-constexpr bool sn_conv_has_bridge() { return SN_PPX && SN_PPX_SEGC == 1 && SPLIT == 1 && NW == 8 && KS == 3 && PCH >= 2 && NF >= SN_PPX_MINNF; }
+constexpr bool sn_conv_has_bridge()
+{
+    return (SN_PPX && SN_PPX_SEGC == 1 && SPLIT == 1 && NW == 8 && KS == 3 && PCH >= 2 && NF >= SN_PPX_MINNF) ||
+           (SN_PP && SPLIT == 2 && K2D == 0 && NW == 8 && KS == 3 && SN_MX_FMT != 0);
+}
 
 // OSPLIT: storage format of the OUTPUT tensor (defaults to SPLIT): lets an f16x3 layer feed an f16m8 layer.
 template <int KS, int DIL, int MF, int NF, int EPI, int SPLIT, int CS8, int PCH_, int NW_, int PADV_, int K2D = 0, int OSPLIT_ = -1>
@@ -521,21 +525,25 @@ conv3d_f16_mfma(ConvArgs a)
     // The next slab's halo tile sits in the OTHER halo buffer and has landed by then (its DMAs are issued in the slab's first piece; the
     // segment in front of the bridge chunk waits vmcnt(0) before its barrier): the bridge entries of the tap table simply carry that buffer's
     // distance. pack_conv_host lays the weights out in the same unit order and decides whether a layer qualifies (a.bridge).
-    constexpr bool BRIDGE_OK = PPX && SPLIT == 1 && SN_PPX_SEGC == 1;
+    // The f16m8 kernels work in PIECES of 8 units (two f16 chunks + one MX step over the same 8): 27 units = 3.375 pieces were run as 4, the
+    // 4th with one chunk, three units and a full-size weight DMA. Bridged, merge_conv_a's 8 slabs are 27 pieces instead of 32 and merge_conv_b's
+    // 13 are 44 instead of 52; the bridge piece is a slab's third or fourth, behind the vmcnt(0) of the second piece's MX load slot.
+    constexpr bool BRIDGE_OK = (PPX && SPLIT == 1 && SN_PPX_SEGC == 1) || PPM;
+    constexpr int UM = SPLIT == 2 ? 8 : 4;                   // units per chunk / per piece: what a slab's unit count is rounded up to
     const bool bridge = BRIDGE_OK && a.bridge != 0;
     // units of slab `slab` in its chunks: GU - o of its own (o: taken by the slab before) + b of the next slab's
     auto slab_units = [&](int c8n, int slab, int &o, int &b) {
         const int GU = C::NTAP * c8n;
         o = 0; b = 0;
         if (bridge) {
-            o = (slab * ((4 - (GU & 3)) & 3)) & 3;
-            b = (slab + 1 == a.nslab) ? 0 : ((4 - ((GU - o) & 3)) & 3);
+            o = (slab * ((UM - (GU & (UM - 1))) & (UM - 1))) & (UM - 1);
+            b = (slab + 1 == a.nslab) ? 0 : ((UM - ((GU - o) & (UM - 1))) & (UM - 1));
         }
         return GU - o + b;
     };
     auto chunks_of = [&](int c8n, int slab) { int o, b; return (slab_units(c8n, slab, o, b) + 3) >> 2; };
     // K-chunks the weight STREAM holds for a slab (f16m8 pads every slab to whole pieces)
-    auto wchunks_of = [&](int c8n, int slab) { return SPLIT == 2 ? (((C::NTAP * c8n + 7) >> 3) << 1) : chunks_of(c8n, slab); };
+    auto wchunks_of = [&](int c8n, int slab) { int o, b; return SPLIT == 2 ? (((slab_units(c8n, slab, o, b) + 7) >> 3) << 1) : chunks_of(c8n, slab); };
     // tap table of slab `slab` (c8n groups) into table buffer kb (= the halo buffer that holds the slab): entry g = LDS byte offset of
     // (tap, group) unit g's 16-byte slot relative to a voxel's own slot
     auto write_koff_part = [&](int c8n, int kb, int slab, int t0, int nt) {

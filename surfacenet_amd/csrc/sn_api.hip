@@ -125,19 +125,20 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
     // same number of channel groups and whose units per slab are not a multiple of 4: the last K-chunk of a slab is filled up with the first
     // b units of the next slab, which starts at its unit o = b
     {
-        bool ok = L.bridge && split == 1 && L.ks == 3 && L.slab_c8.size() >= 2 && (ntap * cs8max) % 4 != 0;
+        const int um = split == 2 ? 8 : 4;                  // units per K-chunk (f16x3) / per weight piece (f16m8)
+        bool ok = L.bridge && (split == 1 || (split == 2 && !L.k2d && SN_MX_FMT != 0)) && L.ks == 3 && L.slab_c8.size() >= 2 && (ntap * cs8max) % um != 0;
         for (unsigned char c8n : L.slab_c8) ok = ok && c8n == cs8max;
         L.bridge = ok ? 1 : 0;
     }
+    const int nslab = (int)L.slab_c8.size();
+    // units of slab si in its chunks / pieces: GU - o of its own + b of the next slab's (the kernel's slab_units)
+    auto slab_units = [&](int si, int c8n, int &o, int &b) {
+        const int GU = ntap * c8n, um = split == 2 ? 8 : 4;
+        o = 0; b = 0;
+        if (L.bridge) { o = (si * ((um - GU % um) % um)) % um; b = (si + 1 == nslab) ? 0 : (um - (GU - o) % um) % um; }
+        return GU - o + b;
+    };
     if (split != 2) {
-        const int nslab = (int)L.slab_c8.size();
-        // units of slab si in its chunks: GU - o of its own + b of the next slab's (the kernel's slab_units)
-        auto slab_units = [&](int si, int c8n, int &o, int &b) {
-            const int GU = ntap * c8n;
-            o = 0; b = 0;
-            if (L.bridge) { o = (si * ((4 - (GU & 3)) & 3)) & 3; b = (si + 1 == nslab) ? 0 : ((4 - ((GU - o) & 3)) & 3); }
-            return GU - o + b;
-        };
         long long chunks = 0;
         for (int si = 0; si < nslab; ++si) { int o, b; chunks += (slab_units(si, L.slab_c8[si], o, b) + 3) / 4; }
         L.wsplit_stride = chunks * nf * 512 * npl;
@@ -171,15 +172,22 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
         }
     } else {
         long long pieces = 0;
-        for (unsigned char c8n : L.slab_c8) pieces += (ntap * c8n + 7) / 8;
+        for (int si = 0; si < nslab; ++si) { int o, b; pieces += (slab_units(si, L.slab_c8[si], o, b) + 7) / 8; }
         const size_t piece_halfs = (size_t)nf * 2048;          // 2 chunks x nf x 1 KiB + nf x 2 KiB = 4*nf KiB
         L.wsplit_stride = pieces * piece_halfs;
         h.assign((size_t)L.wsplit_stride * nsplit, (_Float16)0.f);
         for (int ns = 0; ns < nsplit; ++ns) {
             _Float16 *dst = h.data() + (size_t)ns * L.wsplit_stride;
             int c8_0 = 0;
-            for (unsigned char c8n : L.slab_c8) {
-                const int G = ntap * c8n, npiece = (G + 7) / 8;
+            for (int si = 0; si < nslab; ++si) {
+                const int c8n = L.slab_c8[si];
+                int uo, ub;
+                const int own = slab_units(si, c8n, uo, ub) - ub, G = own + ub, npiece = (G + 7) / 8;
+                // weight of (output channel o, element j) of slot g of this slab's unit sequence: its own units uo.., then ub of the next slab's
+                auto wslot = [&](int o, int g, int j) -> float {
+                    const int u = g < own ? g + uo : g - own, cb = g < own ? c8_0 : c8_0 + c8n;
+                    return wat(o, cb + u % c8n, j, u / c8n);
+                };
                 for (int p = 0; p < npiece; ++p, dst += piece_halfs) {
                     for (int cc = 0; cc < 2; ++cc)
                         for (int f = 0; f < nf; ++f)
@@ -188,7 +196,7 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
                                 const int g = 8 * p + 4 * cc + (lane >> 4);
                                 if (g >= G) continue;
                                 _Float16 *d8 = dst + (((size_t)cc * nf + f) * 64 + lane) * 8;
-                                for (int j = 0; j < 8; ++j) d8[j] = (_Float16)wat(o, c8_0 + g % c8n, j, g / c8n);
+                                for (int j = 0; j < 8; ++j) d8[j] = (_Float16)wslot(o, g, j);
                             }
                     unsigned char *mx = reinterpret_cast<unsigned char *>(dst + (size_t)2 * nf * 512);
                     for (int f = 0; f < nf; ++f)
@@ -209,7 +217,7 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
                                         const bool lo_part = !(pos & 4);
                                         float t = 0.f;
                                         if (g < G) {
-                                            const float w = wat(o, c8_0 + g % c8n, j, g / c8n);
+                                            const float w = wslot(o, g, j);
                                             const float hi = (float)(_Float16)w;
                                             t = lo_part ? (w - hi) * kMxLoMul : hi;
                                         }
@@ -245,7 +253,7 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
                                 const bool lo_part = SN_MX_B128 ? !(i & 1) : q < 2;
                                 if (g >= G) continue;
                                 for (int j = 0; j < 8; ++j) {
-                                    const float w = wat(o, c8_0 + g % c8n, j, g / c8n);
+                                    const float w = wslot(o, g, j);
                                     const float hi = (float)(_Float16)w;
                                     const int kb = i * 8 + j;
                                     frag[(kb >> 4) * 1024 + lane * 16 + (kb & 15)] = lo_part ? fp8_e4m3((w - hi) * kMxLoMul) : fp8_e4m3(hi);
@@ -717,7 +725,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
                 if (m > 0.f && std::isfinite(m)) oe[o] = std::max(-60, std::min(60, -std::ilogb(m)));
             }
         static const bool no_bridge = getenv("SN_NO_BRIDGE") != nullptr;               // (A/B switch)
-        L.bridge = (SN_PPX && lsplit == 1 && k == 3 && !no_bridge) ? 1 : 0;             // f16x3 3x3x3 layers: 27 chunks per four slabs instead of 28 (pack_conv_host decides)
+        L.bridge = (((SN_PPX && lsplit == 1) || (SN_PP && lsplit == 2)) && k == 3 && !no_bridge) ? 1 : 0;   // 27 K-chunks per four slabs instead of 28 (f16x3), 27 weight pieces per eight slabs instead of 32 (f16m8): pack_conv_host decides
         if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit, in_exp, oe.data())) != SN_OK) return rc;
         c->conv[L.name] = L;
     }
