@@ -11,8 +11,9 @@ What is modelled (surfacenet_amd/csrc/mx_format.h, conv3d_mfma.h, sn_api.hip pac
   * storage "x3": value = hi + fp16(value - hi), hi = fp16(value);   storage "m6": hi + q6((value - hi) * 2^11 * 2^s) / 2^(11+s);
   * product "m6" (f16m8 arithmetic): w*x = wh*xh  +  q6b(wl * 2^11) / 2^11 * q6(xh * 2^s) / 2^s  +  q6b(wh) * lo6,
     q6 = fp6 e2m3 (round to nearest even, saturating at 7.5, subnormal step 0.125), q6b = the same with one power-of-two scale per
-    weight block (one output channel x 8 input channels x two consecutive K groups: tap pairs (0,1), (2,3) .. for the 3x3x3 layers,
-    channel-group pairs inside a 5-group slab for the 1x1x1 layers);
+    weight block (one output channel x 8 input channels x two consecutive (tap, group) units of the layer's K stream - group-major, taps
+    inside a group; bridge pieces let a block span two groups - for the 3x3x3 layers, channel-group pairs inside a 5-group slab for the
+    1x1x1 layers);
   * product "x3": exact on the stored values (the device drops lo*lo, 2^-22 relative, and accumulates in fp32).
 How close can device and model be? Stored tensors were compared directly (sn_debug_tensor, round 2, s=16): the concat buffer's fp16 plane
 differs from the model's in 0.24 % of its elements (fp32 vs fp64 upstream: one-ulp flips) and its lo codes in 2.7 %; a flipped (hi, lo)
@@ -76,14 +77,20 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
         O, Cp, Tn = wh.shape
         G = Cp // 8
         a, b = wh.reshape(O, G, 8, Tn), wl.reshape(O, G, 8, Tn)
-        if Tn > 1:                                   # 3x3x3: one channel group per slab, K groups = taps, blocks = tap pairs
-            Tp = Tn + (Tn & 1)
-            pad = lambda z: torch.cat([z, torch.zeros(O, G, 8, Tp - Tn, dtype=td)], dim=3)
-            a, b = pad(a).reshape(O, G, 8, Tp // 2, 2), pad(b).reshape(O, G, 8, Tp // 2, 2)
-            amax = torch.maximum(a.abs().amax(dim=(2, 4)), b.abs().amax(dim=(2, 4)))                   # (O, G, Tp/2)
-            E = block_exp(amax).view(O, G, 1, Tp // 2, 1)
-            aq, bq = q6(a / 2.0 ** E) * 2.0 ** E, q6(b / 2.0 ** E) * 2.0 ** E
-            return aq.reshape(O, G, 8, Tp)[..., :Tn].reshape(O, Cp, Tn), bq.reshape(O, G, 8, Tp)[..., :Tn].reshape(O, Cp, Tn)
+        if Tn > 1:
+            # 3x3x3: one channel group per slab; K is the stream of (tap, group) units, group-major - since the bridge pieces of round 3 a
+            # slab continues where its predecessor stopped, so a block = two CONSECUTIVE units of the whole layer's stream (the pair
+            # (tap 26 of group g, tap 0 of group g + 1) included); only the very end of the stream is padded
+            U = G * Tn
+            Up = U + (U & 1)
+            def stream(z):                           # (O, G, 8, Tn) -> (O, Up / 2, 2, 8)
+                z = z.permute(0, 1, 3, 2).reshape(O, U, 8)
+                return torch.cat([z, torch.zeros(O, Up - U, 8, dtype=td)], dim=1).reshape(O, Up // 2, 2, 8)
+            a, b = stream(a), stream(b)
+            amax = torch.maximum(a.abs().amax(dim=(2, 3)), b.abs().amax(dim=(2, 3)))                   # (O, Up/2)
+            E = block_exp(amax).view(O, Up // 2, 1, 1)
+            back = lambda z: z.reshape(O, Up, 8)[:, :U].reshape(O, G, Tn, 8).permute(0, 1, 3, 2).reshape(O, Cp, Tn)
+            return back(q6(a / 2.0 ** E) * 2.0 ** E), back(q6(b / 2.0 ** E) * 2.0 ** E)
         # 1x1x1: slabs of up to 5 channel groups (tile_for), blocks = consecutive group pairs inside a slab
         aq, bq = torch.zeros_like(a), torch.zeros_like(b)
         g0 = 0
