@@ -103,3 +103,51 @@ def test_host_mx6_encoder_matches_the_format(built, fmt):
     assert enc(top * 1.01, fmt) == 31 and enc(1e30, fmt) == 31 and enc(-1e30, fmt) == 63
     assert enc(vals[1] / 4, fmt) == 0 and enc(float("nan"), fmt) == 0
     assert enc(1.0, 0) == -1
+
+
+def _packed_halfs(cin, ks, taps, cs8, split, nf, nsplit):
+    """Length of pack_conv_host's weight stream, restated: slabs of cs8 channel groups; f16 / f16x3 streams hold K-chunks of 4 (tap, group)
+    units (1 or 2 planes of nf KiB), f16m8 streams pieces of 8 units (4 * nf KiB); bridged layers (f16x3 / f16m8, uniform slabs, units per slab
+    not a multiple of 4 / 8, 3x3(x3) taps) run a slab's units on from where the slab before stopped and pad only the last slab."""
+    groups = -(-cin // 8)
+    slabs = [min(cs8, groups - g) for g in range(0, groups, cs8)]
+    um = 8 if split == 2 else 4
+    bridged = ks == 3 and split in (1, 2) and len(slabs) >= 2 and all(c == cs8 for c in slabs) and (taps * cs8) % um != 0
+    total = 0
+    for si, c8n in enumerate(slabs):
+        gu, o, b = taps * c8n, 0, 0
+        if bridged:
+            o = (si * ((um - gu % um) % um)) % um
+            b = 0 if si + 1 == len(slabs) else (um - (gu - o) % um) % um
+        total += -(-(gu - o + b) // um) * (um // 4)                      # in K-chunks
+    per_chunk = nf * 1024 if split == 2 else nf * 512 * (2 if split == 1 else 1)        # halfs per chunk (f16m8: 4 nf KiB per 2-chunk piece)
+    return total * per_chunk * nsplit, bridged, total
+
+
+@pytest.mark.parametrize("cin,cout,ks,k2d,nf,nsplit,cs8,split,chunks", [
+    (32, 32, 3, 0, 2, 1, 1, 1, 27),        # conv1_2, f16x3: 4 slabs of 27 units = 27 chunks (28 padded)
+    (300, 300, 3, 0, 5, 4, 1, 1, 257),     # conv4_2: 38 slabs -> ceil(38 * 27 / 4)
+    (64, 100, 3, 0, 7, 1, 1, 2, 54),       # merge_conv_a, f16m8: 8 slabs = 27 pieces (32 padded) = 54 chunks
+    (100, 100, 3, 0, 7, 1, 1, 2, 88),      # merge_conv_b: 13 slabs = 44 pieces (52 padded)
+    (64, 64, 3, 1, 4, 1, 2, 1, 18),        # similarityNet 64 -> 64, f16x3: 4 two-group slabs = 18 chunks (20 padded)
+    (64, 64, 3, 1, 4, 1, 4, 0, 18),        # ... its f16 mode: 4-group slabs, 9 chunks each, no bridge needed
+    (6, 32, 3, 0, 2, 1, 1, 1, 7),          # conv1_1: one slab, padded as ever
+    (80, 16, 1, 0, 1, 1, 5, 1, 4),         # a 1x1x1 side conv: never bridged (two 5-group slabs = 1.25 chunks each, padded to 2 + 2)
+])
+def test_packed_weight_stream_length_with_bridge_chunks(built, cin, cout, ks, k2d, nf, nsplit, cs8, split, chunks):
+    import ctypes
+    import numpy as np
+    dbg = ctypes.CDLL(os.path.join(os.path.dirname(built.LIB_PATH), "libsurfacenet_hip_dbg.so"))
+    pack = dbg.sn_debug_pack_host
+    pack.restype = ctypes.c_int
+    pack.argtypes = [ctypes.c_int] * 9 + [ctypes.c_void_p] * 6
+    taps = ks * ks * (1 if k2d else ks)
+    rs = np.random.RandomState(1)
+    W = rs.randn(cout, cin, taps).astype(np.float32)
+    one = np.ones(cout, np.float32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    out = (ctypes.c_ulonglong * 4)()
+    assert pack(cin, cout, ks, 1, k2d, nf, nsplit, cs8, split, P(W), P(one), P(one), P(one), P(one), out) == 0
+    halfs, bridged, total = _packed_halfs(cin, ks, taps, cs8, split, nf, nsplit)
+    assert total == chunks and bridged == (ks == 3 and split != 0 and cin > 8), (total, chunks, bridged)
+    assert out[0] == halfs, (out[0], halfs, bridged)
