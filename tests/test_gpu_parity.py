@@ -406,3 +406,34 @@ def test_epilogue_fusion_equals_separate_launches(gpu_required, tmp_path):
         # f16x3: fp32-class; f16m8: the stand-alone side kernel computes in f16m8, the fused one on three fp16 MFMAs; f16: fp16-class
         tol = 2e-3 if "_f16_" in k else (1e-3 if "_f16m8_" in k else 2e-5)
         assert a.shape == b.shape and np.abs(a - b).max() < tol, (k, float(np.abs(a - b).max()))
+
+
+@pytest.mark.gpu
+def test_bridged_and_padded_k_order_agree(gpu_required, tmp_path):
+    """Bridge chunks / pieces (a slab's last K-chunk or weight piece filled up with the next slab's first (tap, group) units, conv3d_mfma.h
+    slab_units) against the padded order of rounds 1-3 (SN_NO_BRIDGE=1, read once per process -> two subprocesses): the same products, summed
+    in chunks of a different composition, so the probabilities agree to fp32 rounding (f16x3) resp. to the 6-bit block structure (the MX blocks
+    pair other units: f16m8 and the default mode's merge layers)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("", "1"):
+        env = dict(os.environ)
+        env.pop("SN_NO_BRIDGE", None)
+        if flag:
+            env["SN_NO_BRIDGE"] = flag
+        out = str(tmp_path / ("b%s.npz" % flag))
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "ab_outputs.py"), "save", out], env=env, cwd=root)
+        outs.append(np.load(out))
+    worst = {}
+    for k in outs[0].files:
+        a, b = outs[0][k], outs[1][k]
+        d = float(np.abs(a - b).max())
+        mode = "f16" if "_f16_" in k else ("f16m8" if "_f16m8_" in k else "f16x3")
+        worst[mode] = max(worst.get(mode, 0.0), d)
+        assert a.shape == b.shape
+    print("bridged vs padded K order, max |d|:", worst)
+    assert worst["f16"] == 0.0                                   # the f16 mode is not bridged: identical
+    assert 0.0 < worst["f16x3"] < 2e-4 and 0.0 < worst["f16m8"] < 1e-3        # different, and within each mode's parity tolerance of each other
