@@ -575,10 +575,10 @@ conv3d_f16_mfma(ConvArgs a)
     // 2 y-rows x 8 z. PMAP (EPI_SIDEPOOL): wave w owns x in {2(w&3), 2(w&3)+1} x 4 y-rows, so that every 2x2x2 pooling cell lies inside ONE
     // wave (x partner = fragment m+2, y partner = lane^8, z partner = lane^1).
     constexpr bool PMAP = (EPI == EPI_SIDEPOOL);
-    static_assert(!PMAP || (MF == 4 && NW_ == 8 && K2D == 0), "EPI_SIDEPOOL: 8 waves x 4 fragments over an 8x8x8 tile");
+    static_assert(!PMAP || ((MF == 4 || (MF == 8 && SN_PMAP_GAP4)) && NW_ == 8 && K2D == 0), "EPI_SIDEPOOL: 8 waves x 4 (8) fragments over an 8x8x8 (16x8x8) tile");
     auto frag_xyz = [&](int m, int &hx, int &hy, int &hz) {
         if constexpr (C::F4) { hx = wave * MF + m; hy = v >> 2; hz = v & 3; }
-        else if constexpr (PMAP && SN_PMAP_GAP4) { hx = 2 * (wave & 3) + (m >> 1); hy = 2 * (wave >> 2) + (m & 1) + 4 * (v >> 3); hz = v & 7; }
+        else if constexpr (PMAP && SN_PMAP_GAP4) { hx = (MF / 2) * (wave & 3) + (m >> 1); hy = 2 * (wave >> 2) + (m & 1) + 4 * (v >> 3); hz = v & 7; }   // (MF = 8: four x-slices per wave)
         else if constexpr (PMAP) { hx = 2 * (wave & 3) + (m >> 1); hy = 4 * (wave >> 2) + 2 * (m & 1) + (v >> 3); hz = v & 7; }
         else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 4) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
         else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 2) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
@@ -1594,8 +1594,11 @@ conv3d_f16_mfma(ConvArgs a)
             // own format (max(split(y)) == split(max(y)): the hi/lo rounding is monotone, so this equals pooling the stored tensor)
             // SN_PMAP_GAP4: a fragment's rows lie 4 apart (conflict-free LDS reads, lds_probe): wave w owns rows {k, k+1, k+4, k+5}, k = 2 (w >> 2);
             // the y partner is the same lane of fragment m ^ 1, so all four fragments of the wave collapse into ONE pooled value per lane pair
+            // (MF = 8: the wave's fragments 4..7 are a second pair of x-slices: the same once more)
 #pragma unroll
-            for (int mm = 0; mm < (SN_PMAP_GAP4 ? 1 : 2); ++mm) {
+            for (int mset = 0; mset < MF; mset += 4)
+#pragma unroll
+            for (int mm = mset; mm < mset + (SN_PMAP_GAP4 ? 1 : 2); ++mm) {
                 int hx, hy, hz;
                 frag_xyz(mm, hx, hy, hz);
                 const int gx = x0 + hx, gy = y0 + hy, gz = z0 + hz;
@@ -1610,7 +1613,7 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float t = fmaxf(y[mm][n][r], y[mm + 2][n][r]);
-                        if constexpr (SN_PMAP_GAP4) t = fmaxf(t, fmaxf(y[1][n][r], y[3][n][r]));
+                        if constexpr (SN_PMAP_GAP4) t = fmaxf(t, fmaxf(y[mset + 1][n][r], y[mset + 3][n][r]));
                         else t = fmaxf(t, __shfl_xor(t, 8));
                         t = fmaxf(t, __shfl_xor(t, 1));
                         if constexpr (SPLIT == 1) {

@@ -376,6 +376,9 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
 #ifndef SN_C1_MF
 #define SN_C1_MF 8        // voxel fragments per wave of conv1_1 / conv1_2: 8 = 16x8x8 tiles (half the weight staging and weight-fragment reads per MFMA: -6..7 %, A/B r3l), 4-chunk weight pieces - the LDS holds no more
 #endif
+#ifndef SN_C13_MF
+#define SN_C13_MF 8
+#endif
 #define CONV1 3, 1, SN_C1_MF, 2, EPI_STORE, SP, 1, (SP == 2 ? 2 : (SN_C1_MF == 8 ? 4 : 7)), 8, 0
 #define SIDE  1, 1, 4, 1, EPI_STORE, SP, 5, 2, 4, 0
 // conv2_x / conv3_x: 16-channel slabs with one-chunk weight pieces; the ping-pong loop (SN_PPX) needs >= 2 chunks per piece, which fits the
@@ -399,7 +402,8 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     static const bool unfused = getenv("SN_NO_EPI_FUSION") != nullptr;      // A/B measurements: the three separate launches
     if (!unfused) {
         const SideFuse sf1{&L["side_op1"], cat, 64, 0, p1, 32};
-        if (cat_m8) { if constexpr (SP == 1) RUN((launch_conv<3, 1, 4, 2, EPI_SIDEPOOL, 1, 1, 7, 8, 0, 0, 2>(c, L["conv1_3"], b1, 32, none, 0, 0, 32, nullptr, S, s, 0, &sf1))); }
+        // (f16x3: 16x8x8 tiles as conv1_1 / conv1_2, SN_C13_MF = 8: half the weight staging and weight reads per MFMA)
+        if (cat_m8) { if constexpr (SP == 1) RUN((launch_conv<3, 1, SN_C13_MF, 2, EPI_SIDEPOOL, 1, 1, (SN_C13_MF == 8 ? 4 : 7), 8, 0, 0, 2>(c, L["conv1_3"], b1, 32, none, 0, 0, 32, nullptr, S, s, 0, &sf1))); }
         else RUN((launch_conv<3, 1, 4, 2, EPI_SIDEPOOL, SP, 1, (SP == 2 ? 2 : 7), 8, 0>(c, L["conv1_3"], b1, 32, none, 0, 0, 32, nullptr, S, s, 0, &sf1)));
     } else {
         RUN((launch_conv<CONV1>(c, L["conv1_3"], b1, 32, a1, 32, 0, 32, nullptr, S, s)));
