@@ -1764,20 +1764,25 @@ conv3d_f16_mfma(ConvArgs a)
             if constexpr (KS == 1) { if (a.act == 0) store_tile(IntC<0>{}); else store_tile(IntC<1>{}); }
             else store_tile(IntC<0>{});
         } else {
-            // fused merge_conv3: ReLU(BN(acc)) . w3 over the NF*16 channels; the per-channel constants are re-read
-            // per voxel fragment (L1/L2 hits) instead of being kept live, which keeps the kernel within 256 registers
+            // fused merge_conv3: ReLU(BN(acc)) . w3 over the NF*16 channels; the per-channel constants of one cout fragment are fetched once
+            // (L1/L2 hits) and applied to all MF voxel fragments - 3 NF loads per tile instead of 3 NF MF; every p[m] still sums n, r ascending
+            float pm[MF];
+#pragma unroll
+            for (int m = 0; m < MF; ++m) pm[m] = 0.f;
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                const int nl = n * 16 + kq * 4;
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);   // (no stores in flight here: global is fine)
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
+                const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.w3 + nl);
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pm[m] += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
+            }
 #pragma unroll
             for (int m = 0; m < MF; ++m) {
-                float p = 0.f;
-#pragma unroll
-                for (int n = 0; n < NF; ++n) {
-                    const int nl = n * 16 + kq * 4;
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + nl);   // (no stores in flight here: global is fine)
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
-                    const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.w3 + nl);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
-                }
+                float p = pm[m];
                 int hx_, hy_, hz_;
                 frag_xyz(m, hx_, hy_, hz_);
                 const int gx = x0 + hx_, gy = y0 + hy_, gz = z0 + hz_;
