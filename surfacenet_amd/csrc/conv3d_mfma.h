@@ -45,8 +45,11 @@
 #include <stdint.h>
 #include <type_traits>
 
-// Compile-time ablation switches for profiling experiments (results are WRONG when != 0): 1 halo staging only for
-// the first slab, 2 no per-piece barrier, 4 no MFMAs, 16 no weight-fragment reads, 32 no activation-fragment reads.
+// Compile-time ablation switches for profiling experiments (results are WRONG when != 0, except 2048): 1 halo staging only for
+// the first slab, 2 no per-piece barrier, 4 no MFMAs, 16 no weight-fragment reads, 32 no activation-fragment reads (2 .. 32: pipelined
+// loop only), 64 every weight piece = the layer's first (L2-resident), 128 / 256 parts of the pipelined loop's MX step, 512 store epilogues
+// store nothing, 1024 ... store every tile into tile 0's slots, 2048 ... issue every hi-plane store twice (results stay valid),
+// 4096 / 8192 (f16m8 ping-pong loop) every MFMA burst twice / half as long.
 #ifndef SN_ABL
 #define SN_ABL 0
 #endif
