@@ -136,6 +136,20 @@
 #define SN_PP_NOBR 2        // ping-pong loops: weight DMAs issued without per-item / per-piece branches (1: f16m8 loop, 2: f16 / f16x3 loop too): a wave
                             // without an item of its own repeats the piece's last one. merge_conv_a -3..4 %, conv1_x -1.5 %, the rest unchanged (A/B r3w)
 #endif
+#ifndef SN_PW
+#define SN_PW 1           // 1: the f16m8 3x3x3 kernels launched as 4-wave workgroups (NW = 4, MF = 8) run the one-wave-per-SIMD K loop (round 4, see the slab loop)
+#endif
+#ifndef SN_PW_EXP
+#define SN_PW_EXP 0
+#endif
+#ifndef SN_PW_NOSB
+#define SN_PW_NOSB 0
+#endif
+#if SN_PW_NOSB
+#define PW_SB do {} while (0)
+#else
+#define PW_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
 #endif
@@ -293,6 +307,29 @@ __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst_wave_base, 16, (int)voff, 0, 0, 0);
 }
+// MFMAs of the one-wave-per-SIMD loop as inline asm with the accumulator TIED and in the AGPR file ("+a"). Through the builtins hipcc turns two
+// thirds of that loop's 168 MFMAs per piece into their three-address form (result in a fresh register tuple), lets the 224 accumulators drift through
+// the AGPR file and repairs the drift with ~150 v_accvgpr_read / _write per piece, accumulators parked in VGPRs in between. The compiler's hazard
+// recogniser does not look into inline asm: the callers keep every VALU write of an operand >= 2 instructions away and put s_nops between the
+// last MFMA and the epilogue's first accumulator read.
+#define SN_STR_(x) #x
+#define SN_STR(x) SN_STR_(x)
+__device__ __forceinline__ void pw_mfma_f16(f32x4 &c, const half8 &a, const half8 &b)
+{
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// K = 128 MX-scaled step on 6-bit operands (192 bits per lane); OPSEL picks the byte of `sa` that holds the A-side block scale
+template <int OPSEL>
+__device__ __forceinline__ void pw_mfma_mx6(f32x4 &c, const mx_v6i &a, const mx_v6i &b, int sa, int sb)
+{
+    static_assert(OPSEL >= 0 && OPSEL < 4, "scale byte");
+#define SN_MX6_ASM(SEL) "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SEL " cbsz:" SN_STR(SN_MX_FMT) " blgp:" SN_STR(SN_MX_FMT)
+    if constexpr (OPSEL == 0) asm volatile(SN_MX6_ASM("op_sel_hi:[0,0,0]") : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    else if constexpr (OPSEL == 1) asm volatile(SN_MX6_ASM("op_sel:[1,0,0] op_sel_hi:[0,0,0]") : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    else if constexpr (OPSEL == 2) asm volatile(SN_MX6_ASM("op_sel_hi:[1,0,0]") : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    else asm volatile(SN_MX6_ASM("op_sel:[1,0,0] op_sel_hi:[1,0,0]") : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+#undef SN_MX6_ASM
+}
 // Halo-voxel validity bits kept in the top bits of a lane's precomputed halo offset (see stage_halo_buf): a set bit that applies to
 // the tile at hand stays in the offset and pushes it out of the descriptor's range.
 constexpr unsigned HB_ALWAYS = 1u << 31, HB_XLO = 1u << 30, HB_XHI = 1u << 29, HB_YLO = 1u << 28, HB_YHI = 1u << 27, HB_ZLO = 1u << 26,
@@ -321,12 +358,20 @@ struct ConvCfg {
     static constexpr int WBUF = PCH * NF * FRAG;
     static constexpr int NTAP = (K2D ? 1 : KS) * KS * KS;
     static constexpr int KOFF_N = NTAP * CS8MAX + 24;      // + look-ahead padding (2 chunks; f16m8: one 8-group piece; bridged slabs: up to 7 units of the next slab)
+    // one wave per SIMD (conv3d_f16_mfma, PWM loop): 4 waves x (8 voxel x NF cout) fragments, accumulators in AGPRs; the tap tables of ALL slabs
+    // (x both halo buffers) are written once per launch instead of once per slab
+    static constexpr bool PWM = SN_PW && SPLIT == 2 && K2D == 0 && NW_ == 4 && KS == 3 && MF == 8 && SN_MX_FMT != 0 && PCH_ == 2;
+    static constexpr int PW_SLABS = 16;                    // most channel slabs a PWM layer may have (launch_conv checks)
+    // LDS distance of voxel fragment m from fragment 0 of the same lane under the row-gap-4 map (frag_xyz: hx = wave * XS + (m >> 2), hy = (m & 3) + 4 (v >> 3)):
+    // a compile-time constant, so the PWM loop addresses all fragments as one per-lane register + the read's immediate offset
+    static constexpr int pw_xoff(int m) { return (((m >> 2) * HY + (m & 3)) * HZ) * VS; }
+    static constexpr int KTAB_N = PWM ? PW_SLABS * KOFF_N : KOFF_N;   // ints per halo buffer
     static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
     static constexpr int XPLANE = NSEG * 1024;
     static constexpr int XBUF = XPLANE * NPL;
     static constexpr bool CST_LDS = (EPI == EPI_STORE) && NF >= 7;   // wide store epilogues: keep scale/shift in LDS so the compiler's vmcnt(0) before their use cannot serialise the stores (measured: merge_conv_a -4 %, narrower layers +3..6 % -> off there)
     static constexpr int EPI_CONST = CST_LDS ? NF * 16 * 4 * 2 : 0;   // scale, shift of this cout split, fp32
-    static constexpr int LDS_BYTES = 2 * XBUF + 2 * WBUF + 2 * KOFF_N * 4 + EPI_CONST;
+    static constexpr int LDS_BYTES = 2 * XBUF + 2 * WBUF + 2 * KTAB_N * 4 + EPI_CONST;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
     // two 4-wave workgroups per CU only when 256 registers per lane are plausibly enough (accumulators = MF*NF*4)
     static constexpr int WG_PER_CU = (LDS_BYTES <= 80 * 1024 && NW == 4 && MF * NF <= 32) ? 2 : 1;
@@ -336,11 +381,12 @@ struct ConvCfg {
 
 // Does this configuration run the f16 / f16x3 ping-pong loop with bridge chunks (kernel: PPX, BRIDGE_OK)? - the launcher refuses a layer packed
 // with bridge chunks on any other kernel
-template <int KS, int SPLIT, int NW, int PCH, int NF, int K2D>
+template <int KS, int SPLIT, int NW, int PCH, int NF, int K2D, int MF = 4>
 constexpr bool sn_conv_has_bridge()
 {
     return (SN_PPX && SN_PPX_SEGC == 1 && SPLIT == 1 && NW == 8 && KS == 3 && PCH >= 2 && NF >= SN_PPX_MINNF) ||
-           (SN_PP && SPLIT == 2 && K2D == 0 && NW == 8 && KS == 3 && SN_MX_FMT != 0);
+           (SN_PP && SPLIT == 2 && K2D == 0 && NW == 8 && KS == 3 && SN_MX_FMT != 0) ||
+           (SN_PW && SPLIT == 2 && K2D == 0 && NW == 4 && MF == 8 && KS == 3 && PCH == 2 && SN_MX_FMT != 0);
 }
 
 // OSPLIT: storage format of the OUTPUT tensor (defaults to SPLIT): lets an f16x3 layer feed an f16m8 layer.
@@ -354,10 +400,10 @@ conv3d_f16_mfma(ConvArgs a)
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     char *const xbuf = lds;                                   // [2][NPL][XPLANE]
     char *const wbuf = lds + 2 * C::XBUF;                     // [2][WBUF]
-    int *const kbuf = reinterpret_cast<int *>(lds + 2 * C::XBUF + 2 * C::WBUF);   // [2][KOFF_N]
+    int *const kbuf = reinterpret_cast<int *>(lds + 2 * C::XBUF + 2 * C::WBUF);   // [2][KOFF_N]  (PWM: [2][PW_SLABS][KOFF_N])
     // epilogue constants live in LDS: a global load in the epilogue would make hipcc wait vmcnt(0), i.e. for every store
     // issued before it (measured: 21 us per tile of serialised store->load round trips in merge_conv_a)
-    float *const cst = reinterpret_cast<float *>(lds + 2 * C::XBUF + 2 * C::WBUF + 2 * C::KOFF_N * 4);   // [2][NF*16]
+    float *const cst = reinterpret_cast<float *>(lds + 2 * C::XBUF + 2 * C::WBUF + 2 * C::KTAB_N * 4);   // [2][NF*16]
 
     // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to hipcc: without the readfirstlane every
     // loop and LDS-DMA destination indexed by it becomes an EXEC-masked (waterfall) loop (guide T20)
@@ -439,6 +485,8 @@ conv3d_f16_mfma(ConvArgs a)
     constexpr bool PPM = SN_PP && SPLIT == 2 && K2D == 0 && NW_ == 8 && KS == 3 && SN_MX_FMT != 0;   // ping-pong K loop, f16m8 kernels (slab loop)
     constexpr bool PPX = SN_PPX && SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && BUFH && NF >= SN_PPX_MINNF;          // ... f16 / f16x3 kernels
     constexpr bool PP = PPM || PPX;
+    constexpr bool PWM = C::PWM;                   // one wave per SIMD (slab loop)
+    constexpr bool UNI = PP || PWM;                // loops in which hipcc's divergence analysis loses wave-uniform values (stage_halo_buf)
     constexpr unsigned FB_YLO = K2D ? (1u << 31) : HB_YLO, FB_YHI = K2D ? (1u << 30) : HB_YHI, FB_ZLO = K2D ? (1u << 29) : HB_ZLO,
                        FB_ZHI = K2D ? (1u << 28) : HB_ZHI, FB_NEVER = K2D ? 0x0FFFFFF0u : HB_ALWAYS, FB_OFFMASK = K2D ? 0x0FFFFFFFu : HB_OFFMASK;
     unsigned hword[HT];
@@ -484,7 +532,7 @@ conv3d_f16_mfma(ConvArgs a)
     auto stage_halo_buf = [&](int b, unsigned keep, int toff, int c0, int c8n, int xb, int kb = 0, int ke = 1 << 20) -> int {      // [kb, ke): this call's instalment of the wave's HT slots
         // opaque to the optimiser: otherwise it hoists (hword[k] & keep) + toff and the descriptors of BOTH candidate tiles out of the
         // K loop as loop invariants (8 VGPRs + 16 SGPRs live across it) and the accumulators spill
-        if constexpr (PP) {      // (wave-uniform values that hipcc's divergence analysis loses inside the ping-pong piece loop)
+        if constexpr (UNI) {      // (wave-uniform values that hipcc's divergence analysis loses inside the ping-pong piece loop)
             b = __builtin_amdgcn_readfirstlane(b); keep = __builtin_amdgcn_readfirstlane(keep);
             toff = __builtin_amdgcn_readfirstlane(toff); c0 = __builtin_amdgcn_readfirstlane(c0);
         }
@@ -498,7 +546,7 @@ conv3d_f16_mfma(ConvArgs a)
             base0 = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)c0 * VOL * 8 + (size_t)b * D * D * 8);
             nrec = (c8n * (int)VOL - b * D * D) * 16;
         }
-        if constexpr (PP) {      // ... and of the descriptor itself: a buffer_load with a "divergent" resource becomes a waterfall loop
+        if constexpr (UNI) {      // ... and of the descriptor itself: a buffer_load with a "divergent" resource becomes a waterfall loop
             const unsigned long long bq = (unsigned long long)(size_t)base0;
             base0 = (const char *)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bq >> 32)) << 32) |
                                            (unsigned)__builtin_amdgcn_readfirstlane((int)bq));
@@ -531,7 +579,7 @@ conv3d_f16_mfma(ConvArgs a)
     // The f16m8 kernels work in PIECES of 8 units (two f16 chunks + one MX step over the same 8): 27 units = 3.375 pieces were run as 4, the
     // 4th with one chunk, three units and a full-size weight DMA. Bridged, merge_conv_a's 8 slabs are 27 pieces instead of 32 and merge_conv_b's
     // 13 are 44 instead of 52; the bridge piece is a slab's third or fourth, behind the vmcnt(0) of the second piece's MX load slot.
-    constexpr bool BRIDGE_OK = (PPX && SPLIT == 1 && SN_PPX_SEGC == 1) || PPM;
+    constexpr bool BRIDGE_OK = (PPX && SPLIT == 1 && SN_PPX_SEGC == 1) || PPM || PWM;
     constexpr int UM = SPLIT == 2 ? 8 : 4;                   // units per chunk / per piece: what a slab's unit count is rounded up to
     const bool bridge = BRIDGE_OK && a.bridge != 0;
     // units of slab `slab` in its chunks: GU - o of its own (o: taken by the slab before) + b of the next slab's
@@ -552,7 +600,7 @@ conv3d_f16_mfma(ConvArgs a)
     auto write_koff_part = [&](int c8n, int kb, int slab, int t0, int nt) {
         int uo, ub;
         const int own = slab_units(c8n, slab, uo, ub) - ub, nchunk = (own + ub + 3) >> 2;
-        int *k = kbuf + kb * C::KOFF_N;
+        int *k = kbuf + (PWM ? kb * C::PW_SLABS + slab : kb) * C::KOFF_N;
         for (int g = t0; g < (nchunk + 4) * 4; g += nt) {
             int o = 0;
             if (g < own + ub) {
@@ -624,6 +672,10 @@ conv3d_f16_mfma(ConvArgs a)
             tile_halo_consts(x0, y0, z0, keep, toff);
             stage_halo_buf(K2D ? x0 : b, keep, toff, 0, c8n, 0);
         } else stage_halo(tile, 0, c8n, 0, 0, HT);
+        if constexpr (PWM) {      // every slab's tap table, for either halo buffer it may land in (the bridge entries depend on the buffer)
+            for (int kb = 0; kb < 2; ++kb)
+                for (int sl = 0; sl < a.nslab; ++sl) write_koff(a.slab_c8[sl], kb, sl);
+        } else
         write_koff(c8n, 0, 0);
         const int nch = wchunks_of(c8n, 0);
         stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
@@ -675,6 +727,23 @@ conv3d_f16_mfma(ConvArgs a)
         // which merge_conv_a's store epilogue cannot afford (+4 % against the non-ping-pong kernel before this, A/B r3e).
         if constexpr (PP && SN_PP_RESYNC) { if (wave >= C::NW / 2) wg_barrier(); }
         const long long t_tile0 = SN_TIMING == 10 ? __builtin_readcyclecounter() : 0;     // 10: per tile {epilogue, K loop}
+        // PWM: what a piece hands to its successor - the operand fragments of the successor's first f16 chunk (read during the MX burst), the tap
+        // offsets of its second chunk and of its MX step. A tile's first piece loads them cold, right here.
+        half8 pw_xf[PWM ? MF : 1], pw_wf[PWM ? NF : 1];
+        int pw_koB = 0;
+        long long pw_k2 = 0;
+        if constexpr (PWM) {
+            const unsigned tab0 = kbuf_a + (unsigned)((xb * C::PW_SLABS) * (C::KOFF_N * 4));
+            int koA;
+            lds_read32<0>(koA, tab0);
+            lds_read32<16>(pw_koB, tab0);
+            lds_read64<0>(pw_k2, tab0 + kq * 4);
+            lgkm_wait<0>();
+            const unsigned xa = xbuf_a + xb * C::XBUF + (unsigned)xbase[0] + (unsigned)koA, wp0 = wbuf_a + wbi * C::WBUF;
+            static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<C::pw_xoff(m)>(pw_xf[m], xa); });
+            static_for<0, NF>([&](auto nc) { constexpr int n = decltype(nc)::value; lds_read128<n * 1024>(pw_wf[n], wp0); });
+            lgkm_wait<0>();
+        }
         for (int slab = 0; slab < a.nslab; ++slab) {
             const int c8n = a.slab_c8[slab];
             const int nchunk = chunks_of(c8n, slab);
@@ -688,13 +757,174 @@ conv3d_f16_mfma(ConvArgs a)
             const int nc0 = last_slab ? 0 : c0 + c8n;
             const int wchunk = wchunks_of(c8n, slab);
             const size_t nwoff = last_slab ? 0 : woff + (size_t)wchunk * NF * C::FRAG;
-            if constexpr (!PP) { if (have_next) write_koff(nc8n, xb ^ 1, nslab_i); }
+            if constexpr (!PP && !PWM) { if (have_next) write_koff(nc8n, xb ^ 1, nslab_i); }
             // the next halo tile is fetched in npiece-1 instalments, each issued right after a weight piece so that a
             // counted vmcnt can wait for the weights while the newest halo DMAs stay in flight
             // Instalment size HQ is a compile-time constant (sized for a full slab) so that the wait in front of the barrier is a
             // fixed s_waitcnt vmcnt(HQ) or vmcnt(0), one scalar branch; the last instalment of a short slab takes whatever is left.
             int hdone = 0;
 
+            if constexpr (PWM) {
+                // ---- ONE WAVE PER SIMD (round 4): 4 waves x (8 voxel x NF cout) fragments, accumulators in AGPRs ------------------------------
+                // The ping-pong loops below put two waves on a SIMD and let one load while the other computes; every hand-over is a workgroup
+                // barrier (6 per weight piece, each ~100-190 clocks of idle matrix pipe), and a wave's (4 + NF) operand reads serve 4 NF MFMAs.
+                // Here a wave owns the SIMD and 512 registers: 8 x NF accumulator fragments (224 AGPRs), (8 + NF) reads per 8 NF MFMAs - a third fewer
+                // LDS reads per MFMA, half the weight-fragment reads per workgroup - and NOTHING is issued outside an MFMA burst: a piece is three
+                // bursts of 8 NF MFMAs (f16 chunk 2p, f16 chunk 2p+1, the MX step), and behind MFMA i of a burst sits at most one other
+                // instruction - an operand read of the NEXT burst (double-buffered registers), an LDS-DMA of the next weight piece / next halo
+                // tile, a register shuffle of the 6-bit operands (MI355X_MICROARCH.md: a 16-clock MFMA hides ~2 single-issue instructions of its
+                // own wave). sched_barrier(0) behind every pair pins the order. ONE barrier per piece, between the second f16 burst and the MX
+                // burst: by then every wave has read all it needs from the piece's weight buffer (so the piece after next may be fetched into
+                // it) and its share of the next piece's DMAs has landed (the MX burst reads the next piece's first fragments).
+                // Same K order, same MFMAs per accumulator as the ping-pong loop: bit-identical results.
+                static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_B128 && BUFH && DIL == 1 && SN_ROWGAP_3x3 == 4 && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0,
+                              "one-wave-per-SIMD loop: f16m8 3x3x3 kernels");
+                constexpr int mxo = 2 * NF * 1024;
+                constexpr int WCNT = C::PCH * NF * NPL, WPW = (WCNT + C::NW - 1) / C::NW;      // 1 KiB DMAs per weight piece / per wave
+                constexpr int NM = MF * NF;
+                static_assert(20 + 4 * (WPW - 1) < NM && 4 + 2 * NF + 15 < NM, "filler schedule exceeds the burst");
+                const unsigned tab_a = kbuf_a + (unsigned)((xb * C::PW_SLABS + slab) * (C::KOFF_N * 4));
+                const unsigned ntab_a = kbuf_a + (unsigned)(((xb ^ 1) * C::PW_SLABS + nslab_i) * (C::KOFF_N * 4));
+                const unsigned xs_a = xbuf_a + xb * C::XBUF + (unsigned)xbase[0];
+                const unsigned nxs_a = xbuf_a + (xb ^ 1) * C::XBUF + (unsigned)xbase[0];
+                // the halo tile staged during this slab's first piece: the next slab's / the next tile's first slab; behind the launch's last
+                // slab this tile's first slab once more (branch-free issue, the buffer is idle)
+                int hb = have_next ? (last_slab ? nxt_b : b) : b, htoff = have_next ? (last_slab ? nxt_toff : cur_toff) : cur_toff;
+                unsigned hkeep = have_next ? (last_slab ? nxt_keep : cur_keep) : cur_keep;
+                int hc0 = have_next ? nc0 : 0, hc8n = have_next ? nc8n : (int)a.slab_c8[0];
+                hb = __builtin_amdgcn_readfirstlane(hb); htoff = __builtin_amdgcn_readfirstlane(htoff); hkeep = __builtin_amdgcn_readfirstlane(hkeep);
+                hc0 = __builtin_amdgcn_readfirstlane(hc0); hc8n = __builtin_amdgcn_readfirstlane(hc8n);
+                auto halo_rsrc = [&](int plane) {
+                    const char *base = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)hb * VOL * a.in_cs + (size_t)hc0 * VOL * 8) + (plane ? 2 * a.in_lo_off : 0);
+                    const unsigned long long bq = (unsigned long long)(size_t)base;
+                    base = (const char *)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bq >> 32)) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readfirstlane((int)bq));
+                    return __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, __builtin_amdgcn_readfirstlane(hc8n * (int)VOL * 16), 0x00020000);
+                };
+                int p = 0;
+                do {             // (launch_conv: every slab of a PWM layer has at least two pieces)
+                    // ONE loop body for all pieces (a second, specialised copy for the slab's first piece - written out, or peeled off by the optimiser when
+                    // it can see "p == 0" - made hipcc spill 75 registers and shuffle accumulators between the register files around every MFMA)
+                    int p_opaque = p;
+                    asm volatile("" : "+s"(p_opaque));
+                    const bool first = p_opaque == 0;
+                    const unsigned wp = wbuf_a + wbi * C::WBUF, wpn = wbuf_a + (wbi ^ 1) * C::WBUF;
+                    const bool more = p + 1 < npiece;
+                    // the piece after this one: the slab's next, else the first piece of the next slab / tile (tap table and halo tile of the OTHER buffer)
+                    const unsigned nk_a = more ? tab_a + (unsigned)(8 * (p + 1)) * 4 : ntab_a;
+                    const unsigned nx_a = more ? xs_a : nxs_a;
+                    const size_t w_off = more ? woff + (size_t)(2 * p + 2) * NF * C::FRAG : (have_next ? nwoff : 0);
+                    const char *const wsrc = wsrc0 + w_off;
+                    char *const wdst = wbuf + (wbi ^ 1) * C::WBUF;
+                    half8 xfB[MF], wfB[NF];
+                    int koA_n = 0;
+                    // ---- burst A: f16 chunk 2p; behind it: chunk 2p+1's operands, the next piece's tap offsets, the next weight piece's DMAs
+                    const unsigned kosB = xs_a + (unsigned)pw_koB;
+                    static_for<0, NM>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, n = i / MF, m = i % MF;
+                        pw_mfma_f16(acc[m][n], pw_wf[n], pw_xf[m]);
+                        if constexpr (i == 0) lds_read128<NF * 1024>(wfB[0], wp);
+                        else if constexpr (i <= MF) lds_read128<C::pw_xoff(i >= 1 && i <= MF ? i - 1 : 0)>(xfB[i >= 1 && i <= MF ? i - 1 : 0], kosB);
+                        else if constexpr (i < MF + NF) lds_read128<(NF + (i < MF + NF ? i - MF : 0)) * 1024>(wfB[i < MF + NF ? i - MF : 0], wp);
+                        else if constexpr (i >= 20 && (i - 20) % 4 == 0 && (i - 20) / 4 < WPW) {
+                            int it = ((i - 20) / 4) * C::NW + wave;
+                            it = it < WCNT ? it : WCNT - 1;               // (a wave without an item of its own repeats the piece's last one)
+                            dma16(wsrc + (size_t)it * 1024 + lane * 16, wdst + it * 1024);
+                        }
+                        PW_SB;
+                    });
+                    lgkm_wait<0>();
+                    // ---- burst B: f16 chunk 2p+1 (a slab's stream is padded to whole pieces: an absent chunk multiplies zero weights); behind it: the
+                    // MX step's 6-bit weight fragments with their scales, and the code slots of its first two voxel fragments (the others follow
+                    // inside the MX burst, which walks the voxel fragments in its OUTER loop: 3 instead of 8 fragments' slots live at a time)
+                    const unsigned ks0 = xs_a + (unsigned)(int)pw_k2, ks1 = xs_a + (unsigned)(int)(pw_k2 >> 32);
+                    v4i x8h[MF][2], wa4[NF];
+                    long long wb2[NF], wsc;
+                    mx_v6i x8[MF];
+                    // two 12-byte code slots (read whole, 16 bytes each) -> one 192-bit operand: the second slot moves down by one register
+                    auto form_x8 = [&](auto mc) {
+                        constexpr int mm = decltype(mc)::value;
+                        asm volatile("" : "+v"(x8h[mm][0]), "+v"(x8h[mm][1]));
+                        x8[mm] = __builtin_shufflevector(x8h[mm][0], x8h[mm][1], 0, 1, 2, 4, 5, 6);
+                        asm volatile("" : "+v"(x8[mm]));
+                    };
+                    constexpr int RB = 4 + 2 * NF;                        // reads 1 .. RB behind MFMAs 1 .. RB
+                    static_for<0, NM>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, n = i / MF, m = i % MF;
+                        pw_mfma_f16(acc[m][n], wfB[n], xfB[m]);
+                        if constexpr (i == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
+                        else if constexpr (i <= 4) {
+                            constexpr int mm = (i - 1) / 2, sl = (i - 1) & 1;
+                            lds_read128i<C::XPLANE + C::pw_xoff(mm)>(x8h[mm][sl], sl ? ks1 : ks0);
+                        } else if constexpr (i <= RB) {
+                            constexpr int j = i - 5, nn = j / 2;
+                            if constexpr (j & 1) lds_read64<mxo + nn * 2048 + 1024>(wb2[nn], wp);
+                            else lds_read128i<mxo + nn * 2048>(wa4[nn], wp);
+                        } else if constexpr (i == RB + 1) lds_read32<0>(koA_n, nk_a);         // the next piece's tap offsets (ks0 / ks1 hold this piece's)
+                        else if constexpr (i == RB + 2) lds_read32<16>(pw_koB, nk_a);
+                        else if constexpr (i == RB + 3) lds_read64<0>(pw_k2, nk_a + kq * 4);
+                        else if constexpr (i == RB + 12) {
+                            lgkm_wait<0>();
+                        } else if constexpr (i == RB + 13) form_x8(IntC<0>{});
+                        else if constexpr (i == RB + 15) form_x8(IntC<1>{});
+                        PW_SB;
+                    });
+                    // the one barrier of the piece: this wave's part of the next weight piece (issued a burst ago) and, from a slab's second piece on,
+                    // of the next halo tile has landed; nobody reads this piece's weight buffer any more
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    wg_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- burst M: the MX step, voxel fragment m in the outer loop (NF MFMAs each). Behind group m: the code slots of fragment m + 2,
+                    // two operand reads of the NEXT piece's first f16 chunk, the operand of fragment m + 1 formed (its slots were requested a
+                    // group ago: counted wait - LDS returns in order), and (a slab's first piece) one DMA of the next halo tile
+                    typedef int v2i_ __attribute__((ext_vector_type(2)));
+                    mx_v6i wa[NF];
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) {
+                        const v2i_ b2 = __builtin_bit_cast(v2i_, wb2[n]);
+                        const v4i b4 = __builtin_shufflevector(b2, b2, 0, 1, -1, -1);
+                        wa[n] = __builtin_shufflevector(wa4[n], b4, 0, 1, 2, 3, 4, 5);
+                        asm volatile("" : "+v"(wa[n]));
+                    }
+                    int wsc_lo = (int)wsc, wsc_hi = (int)(wsc >> 32);
+                    asm volatile("s_nop 3" : "+v"(wsc_lo), "+v"(wsc_hi));      // (VALU moves that formed the operands above -> first MFMA: the hazard is not visible to hipcc)
+                    const unsigned kosA = nx_a + (unsigned)koA_n;
+                    __amdgpu_buffer_rsrc_t rs_hi, rs_lo;
+                    rs_hi = halo_rsrc(0); rs_lo = halo_rsrc(1);
+                    static_assert(NF >= 7 && HT <= MF, "MX burst: 7 filler slots per voxel fragment");
+                    // next-A read r = 0 .. MF + NF - 1: weight fragment 0, the MF activation fragments, weight fragments 1 .. NF - 1
+                    auto next_a = [&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        if constexpr (r == 0) lds_read128<0>(pw_wf[0], wpn);            // (straight into the carried registers: chunk 2p is long done with them)
+                        else if constexpr (r <= MF) lds_read128<C::pw_xoff(r - 1)>(pw_xf[r - 1], kosA);
+                        else if constexpr (r < MF + NF) lds_read128<(r - MF) * 1024>(pw_wf[r - MF], wpn);
+                    };
+                    static_for<0, NM>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, m = i / NF, n = i % NF;
+                        pw_mfma_mx6<(n & 3)>(acc[m][n], wa[n], x8[m], n < 4 ? wsc_lo : wsc_hi, mx_sb);
+                        if constexpr (n == 0) { if constexpr (m + 2 < MF) lds_read128i<C::XPLANE + C::pw_xoff(m + 2 < MF ? m + 2 : 0)>(x8h[m + 2 < MF ? m + 2 : 0][0], ks0); }
+                        else if constexpr (n == 1) { if constexpr (m + 2 < MF) lds_read128i<C::XPLANE + C::pw_xoff(m + 2 < MF ? m + 2 : 0)>(x8h[m + 2 < MF ? m + 2 : 0][1], ks1); }
+                        else if constexpr (n == 2) next_a(IntC<2 * m>{});
+                        else if constexpr (n == 3) next_a(IntC<2 * m + 1>{});
+                        else if constexpr (n == 4) {
+                            if constexpr (m + 1 < MF) {
+                                // slots of fragment m + 1: read in burst B (m = 0) or behind group m - 1; younger reads: that group's two next-A reads
+                                // and this group's (up to) four
+                                if constexpr (m >= 1) lgkm_wait<2 + (m + 2 < MF ? 4 : 2)>();
+                                form_x8(IntC<(m + 1 < MF ? m + 1 : 0)>{});
+                            }
+                        } else if constexpr (n == 5) {
+                            if constexpr (m < HT) if (first) {
+                                const int li = m * C::NW + wave;                  // (NSEG % NW == 0: the plane of slot m is the same for every wave)
+                                dma16_buf(m * C::NW >= C::NSEG ? rs_lo : rs_hi, (hword[m < HT ? m : 0] & hkeep) + (unsigned)htoff, xbuf + (xb ^ 1) * C::XBUF + li * 1024);
+                            }
+                        }
+                        PW_SB;
+                    });
+                    lgkm_wait<0>();
+                    wbi ^= 1;
+                } while (++p < npiece);
+            } else
             if constexpr (PPX) {
                 // ---- PING-PONG K loop, f16 / f16x3 kernels (round 3) ---------------------------------------------------
                 // Same structure as the f16m8 loop below: a segment = SEGC K-chunks; their NPLM * (MF + NF) operand fragments each are read into
@@ -1399,6 +1629,13 @@ conv3d_f16_mfma(ConvArgs a)
         }
 
         if constexpr (PP && SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }     // pairs with group 1's last compute segment of the tile
+        if constexpr (PWM) {      // the loop's MFMAs are inline asm: the wait states between the last of them and the epilogue's accumulator reads, by hand
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < NF; ++n) asm volatile("" : "+a"(acc[m][n]));
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        }
         const long long t_tile1 = SN_TIMING == 10 ? __builtin_readcyclecounter() : 0;
         if constexpr (SN_TIMING == 10) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- epilogue: folded BN affine + activation --------------------------------------------------------

@@ -434,12 +434,14 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     else RUN((launch_up3<SP>(c, s2, s3, s4, cat, S, s, 64)));
     if constexpr (SP == 1) {
         if (c->tail_m8 >= 2) {
-            RUN((launch_conv<3, 1, 4, 7, EPI_STORE, 2, 1, 2, 8, 0>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
-#ifdef SN_MB_WIDE
-            RUN((launch_conv<3, 1, 8, 7, EPI_FINAL, 2, 1, 2, 4, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
-#else
-            RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
+            // SN_PW (round 4): 4-wave workgroups, one wave per SIMD with 8 x 7 fragment tiles (conv3d_mfma.h, PWM loop); bit 0: merge_conv_a, bit 1: merge_conv_b
+#ifndef SN_PW_LAYERS
+#define SN_PW_LAYERS 3
 #endif
+            if constexpr ((SN_PW != 0) && (SN_PW_LAYERS & 1) != 0) RUN((launch_conv<3, 1, 8, 7, EPI_STORE, 2, 1, 2, 4, 0>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
+            else RUN((launch_conv<3, 1, 4, 7, EPI_STORE, 2, 1, 2, 8, 0>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
+            if constexpr ((SN_PW != 0) && (SN_PW_LAYERS & 2) != 0) RUN((launch_conv<3, 1, 8, 7, EPI_FINAL, 2, 1, 2, 4, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
+            else RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
             return SN_OK;
         }
         if (c->tail_m8 == 1) {
@@ -729,7 +731,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
                 if (m > 0.f && std::isfinite(m)) oe[o] = std::max(-60, std::min(60, -std::ilogb(m)));
             }
         static const bool no_bridge = getenv("SN_NO_BRIDGE") != nullptr;               // (A/B switch)
-        L.bridge = (((SN_PPX && lsplit == 1) || (SN_PP && lsplit == 2)) && k == 3 && !no_bridge) ? 1 : 0;   // 27 K-chunks per four slabs instead of 28 (f16x3), 27 weight pieces per eight slabs instead of 32 (f16m8): pack_conv_host decides
+        L.bridge = (((SN_PPX && lsplit == 1) || ((SN_PP || SN_PW) && lsplit == 2)) && k == 3 && !no_bridge) ? 1 : 0;   // 27 K-chunks per four slabs instead of 28 (f16x3), 27 weight pieces per eight slabs instead of 32 (f16m8): pack_conv_host decides
         if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit, in_exp, oe.data())) != SN_OK) return rc;
         c->conv[L.name] = L;
     }

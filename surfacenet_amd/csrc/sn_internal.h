@@ -271,8 +271,13 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     }
     a.nslab = (int)L.slab_c8.size();
     a.bridge = L.bridge;
-    if (L.bridge && !sn::sn_conv_has_bridge<KS, SPLIT, NW, PCH, NF, K2D>())
+    if (L.bridge && !sn::sn_conv_has_bridge<KS, SPLIT, NW, PCH, NF, K2D, MF>())
         return fail(SN_ERR_STATE, "%s: packed with bridge chunks, launched on a kernel without them", L.name.c_str());
+    if (C::PWM) {      // one-wave-per-SIMD loop: all tap tables live in LDS; a slab's first piece issues DMAs that its second piece waits for
+        if (a.nslab > C::PW_SLABS) return fail(SN_ERR_STATE, "%s: %d channel slabs exceed the %d this kernel keeps tap tables for", L.name.c_str(), a.nslab, C::PW_SLABS);
+        for (unsigned char c8n : L.slab_c8)
+            if (C::NTAP * c8n < 9) return fail(SN_ERR_STATE, "%s: a channel slab of fewer than two weight pieces", L.name.c_str());
+    }
     for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
     const double vox = (double)B * DX * D * D;
     const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : (EPI == EPI_SIDEPOOL ? 16 + L.cout / 8.0 : L.cout)));
