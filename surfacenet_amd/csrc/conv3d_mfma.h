@@ -192,7 +192,10 @@ struct ConvArgs {
     int stagger_clk;      // start delay (shader clocks) per phase step: workgroups start in 4 phases so that their
                           // epilogue store bursts do not hit HBM at the same instant (0 = off)
     int nslab;
-    unsigned char slab_c8[kMaxSlab];  // 8-channel groups per slab
+    int c8_last;          // 8-channel groups of the layer's LAST channel slab; every other slab holds the kernel's CS8 (pack_conv_host cuts them that way).
+                          // (Round 4: the table of per-slab sizes this replaces lived in the kernel-argument segment, and "slab_c8[slab]" with a run-time
+                          // index was a global_load_ubyte + s_waitcnt vmcnt(0) at EVERY slab boundary - a wait for all LDS-DMAs in flight plus a memory
+                          // round trip, ~500 clocks twice per slab with the matrix pipe idle.)
     int bridge;           // f16x3 kernels on the ping-pong loop: a slab's last K-chunk is filled up with the next slab's first units (write_koff_part)
 };
 
@@ -301,6 +304,12 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_dst_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_dst_wave_base, 16, 0, AUX);
 }
 
+// The same in the instruction's scalar-base form, M0 set by hand: lane l's 16 bytes from sbase + voff(l) land at lds_dst + 16 l. One SALU op (M0), no
+// per-lane 64-bit address arithmetic per DMA (the one-wave-per-SIMD loop issues its DMAs between MFMAs, where every instruction counts).
+__device__ __forceinline__ void dma16_s(const void *sbase, unsigned voff, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
 // The same through a buffer descriptor: lanes whose byte offset fails the descriptor's range check (offset >= num_records, which
 // includes "negative" offsets) deposit ZEROS in LDS (tools/probe/buflds_probe.hip) - the hardware does the 'same' padding.
 __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, void *lds_dst_wave_base)
@@ -414,6 +423,7 @@ conv3d_f16_mfma(ConvArgs a)
     const int D = a.D, DX = a.DX;
     const size_t VOL = (size_t)DX * D * D;
     const int tstride = gridDim.x;
+    auto slab_c8_of = [&](int sl) -> int { return sl + 1 == a.nslab ? a.c8_last : C::CS8MAX; };      // channel groups of slab sl (scalar arithmetic only)
 #if SN_XCD_REMAP
     // XCD-aware walk (speed only): workgroup i is observed to run on XCD i % 8; within each round of gridDim.x tiles XCD x
     // takes the contiguous run [x*G/8, (x+1)*G/8) so that neighbouring tiles (shared halos) meet in one L2.
@@ -664,7 +674,7 @@ conv3d_f16_mfma(ConvArgs a)
     }
     // ---- prologue: first halo tile, its tap table, first weight piece ----------------------------------------
     {
-        const int c8n = a.slab_c8[0];
+        const int c8n = slab_c8_of(0);
         if constexpr (BUFH) {
             int b, x0, y0, z0, toff;
             unsigned keep;
@@ -674,7 +684,7 @@ conv3d_f16_mfma(ConvArgs a)
         } else stage_halo(tile, 0, c8n, 0, 0, HT);
         if constexpr (PWM) {      // every slab's tap table, for either halo buffer it may land in (the bridge entries depend on the buffer)
             for (int kb = 0; kb < 2; ++kb)
-                for (int sl = 0; sl < a.nslab; ++sl) write_koff(a.slab_c8[sl], kb, sl);
+                for (int sl = 0; sl < a.nslab; ++sl) write_koff(slab_c8_of(sl), kb, sl);
         } else
         write_koff(c8n, 0, 0);
         const int nch = wchunks_of(c8n, 0);
@@ -730,6 +740,7 @@ conv3d_f16_mfma(ConvArgs a)
         // PWM: what a piece hands to its successor - the operand fragments of the successor's first f16 chunk (read during the MX burst), the tap
         // offsets of its second chunk and of its MX step. A tile's first piece loads them cold, right here.
         half8 pw_xf[PWM ? MF : 1], pw_wf[PWM ? NF : 1];
+        const unsigned pw_wv = (unsigned)(wave * 1024 + lane * 16);      // this lane's bytes within this wave's first KiB of a weight piece (weight DMAs)
         int pw_koB = 0;
         long long pw_k2 = 0;
         if constexpr (PWM) {
@@ -745,7 +756,7 @@ conv3d_f16_mfma(ConvArgs a)
             lgkm_wait<0>();
         }
         for (int slab = 0; slab < a.nslab; ++slab) {
-            const int c8n = a.slab_c8[slab];
+            const int c8n = slab_c8_of(slab);
             const int nchunk = chunks_of(c8n, slab);
             const int npiece = (nchunk + C::PCH - 1) / C::PCH;
             // what comes after this slab: next slab of this tile, or slab 0 of this workgroup's next tile
@@ -753,7 +764,7 @@ conv3d_f16_mfma(ConvArgs a)
             const int ntile = last_slab ? tile + tstride : tile;
             const bool have_next = ntile < a.total_tiles;
             const int nslab_i = last_slab ? 0 : slab + 1;
-            const int nc8n = a.slab_c8[nslab_i];
+            const int nc8n = slab_c8_of(nslab_i);
             const int nc0 = last_slab ? 0 : c0 + c8n;
             const int wchunk = wchunks_of(c8n, slab);
             const size_t nwoff = last_slab ? 0 : woff + (size_t)wchunk * NF * C::FRAG;
@@ -779,10 +790,12 @@ conv3d_f16_mfma(ConvArgs a)
                 // Same K order, same MFMAs per accumulator as the ping-pong loop: bit-identical results.
                 static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_B128 && BUFH && DIL == 1 && SN_ROWGAP_3x3 == 4 && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0,
                               "one-wave-per-SIMD loop: f16m8 3x3x3 kernels");
+                long long pws0 = 0, pws1 = 0;          // SN_TIMING 4: per slab {everything in front of the piece loop since the previous slab's last piece, the piece loop}
+                if constexpr (SN_TIMING == 4) { pws0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                 constexpr int mxo = 2 * NF * 1024;
                 constexpr int WCNT = C::PCH * NF * NPL, WPW = (WCNT + C::NW - 1) / C::NW;      // 1 KiB DMAs per weight piece / per wave
                 constexpr int NM = MF * NF;
-                static_assert(20 + 4 * (WPW - 1) < NM && 4 + 2 * NF + 15 < NM, "filler schedule exceeds the burst");
+                static_assert(16 + 3 * (WPW + HT / 2 - 1) < NM && 4 + 2 * NF + 15 < NM, "filler schedule exceeds the burst");
                 const unsigned tab_a = kbuf_a + (unsigned)((xb * C::PW_SLABS + slab) * (C::KOFF_N * 4));
                 const unsigned ntab_a = kbuf_a + (unsigned)(((xb ^ 1) * C::PW_SLABS + nslab_i) * (C::KOFF_N * 4));
                 const unsigned xs_a = xbuf_a + xb * C::XBUF + (unsigned)xbase[0];
@@ -791,7 +804,7 @@ conv3d_f16_mfma(ConvArgs a)
                 // slab this tile's first slab once more (branch-free issue, the buffer is idle)
                 int hb = have_next ? (last_slab ? nxt_b : b) : b, htoff = have_next ? (last_slab ? nxt_toff : cur_toff) : cur_toff;
                 unsigned hkeep = have_next ? (last_slab ? nxt_keep : cur_keep) : cur_keep;
-                int hc0 = have_next ? nc0 : 0, hc8n = have_next ? nc8n : (int)a.slab_c8[0];
+                int hc0 = have_next ? nc0 : 0, hc8n = have_next ? nc8n : slab_c8_of(0);
                 hb = __builtin_amdgcn_readfirstlane(hb); htoff = __builtin_amdgcn_readfirstlane(htoff); hkeep = __builtin_amdgcn_readfirstlane(hkeep);
                 hc0 = __builtin_amdgcn_readfirstlane(hc0); hc8n = __builtin_amdgcn_readfirstlane(hc8n);
                 auto halo_rsrc = [&](int plane) {
@@ -801,7 +814,13 @@ conv3d_f16_mfma(ConvArgs a)
                                                   (unsigned)__builtin_amdgcn_readfirstlane((int)bq));
                     return __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, __builtin_amdgcn_readfirstlane(hc8n * (int)VOL * 16), 0x00020000);
                 };
+                // halo descriptors of the slab staged during this one: the f16 plane goes out with the slab's first piece, the code plane with its second
+                static_assert(HT % 2 == 0 && C::NSEG * NPL == HT * C::NW && (HT / 2) * C::NW == C::NSEG && WCNT % C::NW == 0, "PWM DMA schedule");
+                constexpr int HH = HT / 2;
+                const __amdgpu_buffer_rsrc_t rs_hi = halo_rsrc(0), rs_lo = halo_rsrc(1);
+                const unsigned hdst = lds_addr(xbuf) + (unsigned)((xb ^ 1) * C::XBUF + wave * 1024);      // + k * NW KiB: this wave's k-th halo segment
                 int p = 0;
+                if constexpr (SN_TIMING == 4) { pws1 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (t_rel != 0) t_vm += pws1 - t_rel; }
                 do {             // (launch_conv: every slab of a PWM layer has at least two pieces)
                     // ONE loop body for all pieces (a second, specialised copy for the slab's first piece - written out, or peeled off by the optimiser when
                     // it can see "p == 0" - made hipcc spill 75 registers and shuffle accumulators between the register files around every MFMA)
@@ -815,9 +834,17 @@ conv3d_f16_mfma(ConvArgs a)
                     const unsigned nx_a = more ? xs_a : nxs_a;
                     const size_t w_off = more ? woff + (size_t)(2 * p + 2) * NF * C::FRAG : (have_next ? nwoff : 0);
                     const char *const wsrc = wsrc0 + w_off;
-                    char *const wdst = wbuf + (wbi ^ 1) * C::WBUF;
+                    const unsigned wdst_a = lds_addr(wbuf) + (unsigned)((wbi ^ 1) * C::WBUF + wave * 1024);
+                    const bool halo_now = p_opaque < 2;           // (pieces 0 and 1 of the slab carry the next halo tile's DMAs)
+                    __amdgpu_buffer_rsrc_t rs_p = first ? rs_hi : rs_lo;
+                    unsigned hdst_p = hdst + (first ? 0u : (unsigned)(HH * C::NW * 1024));
+                    asm volatile("" : "+s"(rs_p), "+s"(hdst_p));
                     half8 xfB[MF], wfB[NF];
                     int koA_n = 0;
+                    // SN_TIMING (diagnostic builds; PWM loop): 1 {burst A, burst B}, 2 {vmcnt wait, barrier}, 3 {burst M, whole piece} per piece
+                    long long pwt[6] = {0, 0, 0, 0, 0, 0};
+#define PW_T(i) do { if constexpr (SN_TIMING >= 1 && SN_TIMING <= 3) { pwt[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
+                    PW_T(0);
                     // ---- burst A: f16 chunk 2p; behind it: chunk 2p+1's operands, the next piece's tap offsets, the next weight piece's DMAs
                     const unsigned kosB = xs_a + (unsigned)pw_koB;
                     static_for<0, NM>([&](auto ic) {
@@ -826,14 +853,25 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (i == 0) lds_read128<NF * 1024>(wfB[0], wp);
                         else if constexpr (i <= MF) lds_read128<C::pw_xoff(i >= 1 && i <= MF ? i - 1 : 0)>(xfB[i >= 1 && i <= MF ? i - 1 : 0], kosB);
                         else if constexpr (i < MF + NF) lds_read128<(NF + (i < MF + NF ? i - MF : 0)) * 1024>(wfB[i < MF + NF ? i - MF : 0], wp);
-                        else if constexpr (i >= 20 && (i - 20) % 4 == 0 && (i - 20) / 4 < WPW) {
-                            int it = ((i - 20) / 4) * C::NW + wave;
-                            it = it < WCNT ? it : WCNT - 1;               // (a wave without an item of its own repeats the piece's last one)
-                            dma16(wsrc + (size_t)it * 1024 + lane * 16, wdst + it * 1024);
+                        else if constexpr (i >= 16 && (i - 16) % 3 == 0 && (i - 16) / 3 < WPW + HH) {
+                            constexpr int q = (i - 16) / 3;                  // DMA slot q of the burst: weights and halo segments alternate while both last
+                            constexpr bool is_h = (q % 2 == 1) && (q / 2 < HH);
+                            if constexpr (!is_h) {
+                                constexpr int k = q < 2 * HH ? q / 2 : q - HH;      // this wave's k-th KiB of the next weight piece
+                                dma16_s(wsrc, pw_wv + k * (C::NW * 1024), wdst_a + k * (C::NW * 1024));
+                            } else {
+                                constexpr int j = q / 2;
+                                if (halo_now) {
+                                    const unsigned hw = first ? hword[j] : hword[HH + j];
+                                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(hdst_p + (unsigned)(j * C::NW * 1024)),
+                                                 "v"((hw & hkeep) + (unsigned)htoff), "s"(rs_p) : "memory");
+                                }
+                            }
                         }
                         PW_SB;
                     });
                     lgkm_wait<0>();
+                    PW_T(1);
                     // ---- burst B: f16 chunk 2p+1 (a slab's stream is padded to whole pieces: an absent chunk multiplies zero weights); behind it: the
                     // MX step's 6-bit weight fragments with their scales, and the code slots of its first two voxel fragments (the others follow
                     // inside the MX burst, which walks the voxel fragments in its OUTER loop: 3 instead of 8 fragments' slots live at a time)
@@ -871,8 +909,11 @@ conv3d_f16_mfma(ConvArgs a)
                     });
                     // the one barrier of the piece: this wave's part of the next weight piece (issued a burst ago) and, from a slab's second piece on,
                     // of the next halo tile has landed; nobody reads this piece's weight buffer any more
+                    PW_T(2);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PW_T(3);
                     wg_barrier();
+                    PW_T(4);
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- burst M: the MX step, voxel fragment m in the outer loop (NF MFMAs each). Behind group m: the code slots of fragment m + 2,
                     // two operand reads of the NEXT piece's first f16 chunk, the operand of fragment m + 1 formed (its slots were requested a
@@ -889,8 +930,6 @@ conv3d_f16_mfma(ConvArgs a)
                     int wsc_lo = (int)wsc, wsc_hi = (int)(wsc >> 32);
                     asm volatile("s_nop 3" : "+v"(wsc_lo), "+v"(wsc_hi));      // (VALU moves that formed the operands above -> first MFMA: the hazard is not visible to hipcc)
                     const unsigned kosA = nx_a + (unsigned)koA_n;
-                    __amdgpu_buffer_rsrc_t rs_hi, rs_lo;
-                    rs_hi = halo_rsrc(0); rs_lo = halo_rsrc(1);
                     static_assert(NF >= 7 && HT <= MF, "MX burst: 7 filler slots per voxel fragment");
                     // next-A read r = 0 .. MF + NF - 1: weight fragment 0, the MF activation fragments, weight fragments 1 .. NF - 1
                     auto next_a = [&](auto rc) {
@@ -913,17 +952,18 @@ conv3d_f16_mfma(ConvArgs a)
                                 if constexpr (m >= 1) lgkm_wait<2 + (m + 2 < MF ? 4 : 2)>();
                                 form_x8(IntC<(m + 1 < MF ? m + 1 : 0)>{});
                             }
-                        } else if constexpr (n == 5) {
-                            if constexpr (m < HT) if (first) {
-                                const int li = m * C::NW + wave;                  // (NSEG % NW == 0: the plane of slot m is the same for every wave)
-                                dma16_buf(m * C::NW >= C::NSEG ? rs_lo : rs_hi, (hword[m < HT ? m : 0] & hkeep) + (unsigned)htoff, xbuf + (xb ^ 1) * C::XBUF + li * 1024);
-                            }
                         }
                         PW_SB;
                     });
                     lgkm_wait<0>();
+                    PW_T(5);
+#undef PW_T
+                    if constexpr (SN_TIMING == 1) { t_vm += pwt[1] - pwt[0]; t_bar += pwt[2] - pwt[1]; ++n_piece; }
+                    if constexpr (SN_TIMING == 2) { t_vm += pwt[3] - pwt[2]; t_bar += pwt[4] - pwt[3]; ++n_piece; }
+                    if constexpr (SN_TIMING == 3) { t_vm += pwt[5] - pwt[4]; t_bar += pwt[5] - pwt[0]; ++n_piece; }
                     wbi ^= 1;
                 } while (++p < npiece);
+                if constexpr (SN_TIMING == 4) { t_rel = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_bar += t_rel - pws1; ++n_piece; if (last_slab) t_rel = 0; }
             } else
             if constexpr (PPX) {
                 // ---- PING-PONG K loop, f16 / f16x3 kernels (round 3) ---------------------------------------------------
@@ -991,7 +1031,7 @@ conv3d_f16_mfma(ConvArgs a)
                                     const bool real = w_next;
                                     const char *src = wsrc0 + (real ? w_off : 0);
                                     char *dst = wbuf + (wbi ^ 1) * C::WBUF;
-                                    const int nch0 = wchunks_of(a.slab_c8[0], 0);
+                                    const int nch0 = wchunks_of(slab_c8_of(0), 0);
                                     const int cnt = (real ? w_nch : (nch0 < C::PCH ? nch0 : C::PCH)) * NF * NPL;
                                     constexpr int WPWX = (C::PCH * NF * NPL + C::NW - 1) / C::NW;
                                     static_for<0, WPWX>([&](auto kc) {

@@ -278,7 +278,9 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
         for (unsigned char c8n : L.slab_c8)
             if (C::NTAP * c8n < 9) return fail(SN_ERR_STATE, "%s: a channel slab of fewer than two weight pieces", L.name.c_str());
     }
-    for (int i = 0; i < a.nslab; ++i) a.slab_c8[i] = L.slab_c8[i];
+    for (int i = 0; i + 1 < a.nslab; ++i)
+        if (L.slab_c8[i] != C::CS8MAX) return fail(SN_ERR_STATE, "%s: channel slab %d holds %d groups, the kernel expects %d in all but the last", L.name.c_str(), i, (int)L.slab_c8[i], C::CS8MAX);
+    a.c8_last = L.slab_c8.back();
     const double vox = (double)B * DX * D * D;
     const double bytes = vox * 2.0 * (SPLIT ? 2 : 1) * (L.cin + (EPI == EPI_FINAL ? 2 : (EPI == EPI_SIDEPOOL ? 16 + L.cout / 8.0 : L.cout)));
     ProfScope ps(c, L.name, 2.0 * L.macs_per_voxel * vox, bytes);
