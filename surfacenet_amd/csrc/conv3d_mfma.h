@@ -139,17 +139,8 @@
 #ifndef SN_PW
 #define SN_PW 1           // 1: the f16m8 3x3x3 kernels launched as 4-wave workgroups (NW = 4, MF = 8) run the one-wave-per-SIMD K loop (round 4, see the slab loop)
 #endif
-#ifndef SN_PW_EXP
-#define SN_PW_EXP 0
-#endif
-#ifndef SN_PW_NOSB
-#define SN_PW_NOSB 0
-#endif
-#if SN_PW_NOSB
-#define PW_SB do {} while (0)
-#else
+// PWM loop: sched_barrier(0) behind every (MFMA, filler) pair pins the written order
 #define PW_SB __builtin_amdgcn_sched_barrier(0)
-#endif
 #ifndef SN_SETPRIO
 #define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
 #endif
@@ -790,8 +781,7 @@ conv3d_f16_mfma(ConvArgs a)
                 // Same K order, same MFMAs per accumulator as the ping-pong loop: bit-identical results.
                 static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_B128 && BUFH && DIL == 1 && SN_ROWGAP_3x3 == 4 && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0,
                               "one-wave-per-SIMD loop: f16m8 3x3x3 kernels");
-                long long pws0 = 0, pws1 = 0;          // SN_TIMING 4: per slab {everything in front of the piece loop since the previous slab's last piece, the piece loop}
-                if constexpr (SN_TIMING == 4) { pws0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                long long pws1 = 0;                    // SN_TIMING 4: per slab {everything in front of the piece loop since the previous slab's last piece, the piece loop}
                 constexpr int mxo = 2 * NF * 1024;
                 constexpr int WCNT = C::PCH * NF * NPL, WPW = (WCNT + C::NW - 1) / C::NW;      // 1 KiB DMAs per weight piece / per wave
                 constexpr int NM = MF * NF;
