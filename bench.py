@@ -228,8 +228,11 @@ def main():
     ap.add_argument("--n-vp", type=int, default=2)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x3p", "f16m8", "f16"],
                     help="f16x3 (default): hi/lo split fp16 operands, fp32-class results (parity grade); f16: fast mode, L_inf ~2e-3")
-    ap.add_argument("--native-comm", action="store_true", help="N>1: all-gather through the library's own RCCL binding (sn_comm_init / sn_allgather_f32_dev, "
-                    "in-order on the context's stream) instead of torch.distributed's; torch.distributed still carries the 128-byte id and the barriers")
+    ap.add_argument("--torch-comm", action="store_true", help="N>1: all-gather through torch.distributed instead of the library's own RCCL binding (the default: "
+                    "sn_comm_init / sn_allgather_f32_dev_overlap on the context's communication stream, overlapping the next step's kernels; torch.distributed "
+                    "still carries the 128-byte id and the barriers). The native path is checked against torch's result before the timed region and the "
+                    "bench falls back to torch.distributed - saying so in its JSON line - if it cannot be set up")
+    ap.add_argument("--native-comm", action="store_true", help=argparse.SUPPRESS)      # (the default since round 4; kept for old command lines)
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16 fast-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-s64", action="store_true", help="skip the extra s=64 measurement")
@@ -276,14 +279,35 @@ def main():
     ctx.set_cameras(scene["cams"])
     ctx.set_images(scene["imgs"])
     d_pairs, d_xyz, d_resol, d_w = (ctx.upload(scene[k]) for k in ("pairs", "xyz", "resol", "w"))
-    native = use_dist and (args.native_comm or bool(os.environ.get("BENCH_NATIVE_COMM")))
+    native = use_dist and not (args.torch_comm or bool(os.environ.get("BENCH_TORCH_COMM")))
+    comm_note = None
     if native:
-        # the C ABI's own exchange: rank 0 draws the RCCL unique id, torch.distributed ships its 128 bytes, every rank joins
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(surfacenet_amd.Context.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, src=0)
-        ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        # the C ABI's own exchange: rank 0 draws the RCCL unique id, torch.distributed ships its 128 bytes, every rank joins; then one small
+        # all-gather through the library is compared with torch.distributed's. Any failure on any rank -> every rank falls back to torch.
+        ok, why = 1, ""
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(surfacenet_amd.Context.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+            probe = (np.arange(4096, dtype=np.float32) + 10000.0 * rank)
+            d_p, d_pg = ctx.upload(probe), ctx.dev_alloc(world * probe.nbytes)
+            ctx.allgather_f32_dev_overlap(d_p, probe.size, d_pg, 7)
+            ctx.synchronize()
+            got = np.empty((world * probe.size,), np.float32)
+            ctx.d2h(got, d_pg)
+            want = np.concatenate([np.arange(4096, dtype=np.float32) + 10000.0 * r for r in range(world)])
+            if not np.array_equal(got, want):
+                ok, why = 0, "native all-gather returned wrong data"
+            ctx.dev_free(d_p); ctx.dev_free(d_pg)
+        except Exception as e:      # noqa: BLE001 - whatever went wrong, the scaling run must still produce a number
+            ok, why = 0, "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            native, comm_note = False, "native RCCL binding unavailable (%s): torch.distributed all-gather instead" % (why or "another rank failed")
+    if native:
         d_fused = [ctx.dev_alloc(n * s3 * 4) for _ in range(2)]
         d_all = [ctx.dev_alloc(world * n * s3 * 4) for _ in range(2)]
     elif use_dist:
@@ -303,8 +327,9 @@ def main():
         b = step_no[0] & 1
         step_no[0] += 1
         if native:
+            ctx.comm_wait(b)                                               # the all-gather that read this buffer pair two steps ago
             ctx.cvc_forward_dev(n, n_vp, d_pairs, d_xyz, d_resol, d_w, d_fused[b])
-            ctx.allgather_f32_dev(d_fused[b], n * s3, d_all[b])            # RCCL, in order on the context's stream
+            ctx.allgather_f32_dev_overlap(d_fused[b], n * s3, d_all[b], b)   # RCCL on the context's communication stream: overlaps the next step's kernels
             return
         if use_dist and gathered[b] is not None:
             sn_stream.wait_event(gathered[b])      # the all-gather that read this buffer two steps ago must be done first
@@ -362,7 +387,8 @@ def main():
             "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": "synthetic 2-view 1600x1200, s=%d, batch=%d cubes/GPU, N_viewpair=%d (%s)" % (
                 s, n, n_vp, "BASELINE.json configs[1]" if (s, n, n_vp) == (32, 64, 2) else ("one GPU's shard of BASELINE.json configs[3]: s=64, 256 cubes over 8 GPUs" if (s, n) == (64, 32) else "non-default workload")),
-                       "cubes_per_gpu": n, "samples_per_step": n * n_vp * world, "parallelism": "cube-sharded x%d%s" % (world, (", RCCL all-gather of fused probabilities" + (" (native sn_allgather_f32_dev)" if native else " (torch.distributed)")) if world > 1 else "")},
+                       "cubes_per_gpu": n, "samples_per_step": n * n_vp * world, "parallelism": "cube-sharded x%d%s" % (world, (", RCCL all-gather of fused probabilities" + (" (native sn_allgather_f32_dev_overlap)" if native else " (torch.distributed)")) if world > 1 else ""),
+                       **({"comm_note": comm_note} if comm_note else {})},
             "roofline": {"bound": "mfma", "kernel": "conv3d_f16_mfma<%s>" % dom, "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                          "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],

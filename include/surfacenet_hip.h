@@ -224,6 +224,17 @@ SN_API int sn_project_points(sn_ctx *ctx, int V, const double *P, int n, const d
 SN_API int sn_comm_unique_id(char *id128);
 SN_API int sn_comm_init(sn_ctx *ctx, int world, int rank, const char *id128);
 SN_API int sn_allgather_f32_dev(sn_ctx *ctx, const float *local_dev, size_t n_local, float *global_dev);
+/* The same on the context's own communication stream, ordered behind everything submitted to the kernel stream so far: the all-gather of
+ * batch i overlaps the kernels of batch i + 1. slot (0..7) names its completion; sn_comm_wait(ctx, slot) makes the kernel stream wait for it
+ * (call it before local_dev / global_dev are written again). sn_synchronize waits for both streams. */
+SN_API int sn_allgather_f32_dev_overlap(sn_ctx *ctx, const float *local_dev, size_t n_local, float *global_dev, int slot);
+SN_API int sn_comm_wait(sn_ctx *ctx, int slot);
+/* Variable-length all-gather of bytes - the exchange of the packed sparse voxel lists of a sharded scene (SURVEY §8e "counts then
+ * all-gather-v"; utils/sparseCubes.py:9-77 produces the lists, main_reconstruct.py:153-160 accumulates them): every rank contributes
+ * n_local bytes of device memory (0 allowed, different per rank); global_dev receives the contributions back to back in rank order and
+ * counts[r] (host, `world` entries) their sizes. Synchronous. SN_ERR_ARG with counts[] filled when global_cap is too small. */
+SN_API int sn_allgatherv_bytes_dev(sn_ctx *ctx, const void *local_dev, size_t n_local, void *global_dev, size_t global_cap,
+                                   unsigned long long *counts);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Per-kernel HIP-event timing on the context's stream. While enabled every kernel launch is

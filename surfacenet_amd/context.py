@@ -336,9 +336,50 @@ class Context(object):
 
     def comm_init(self, world, rank, unique_id):
         _lib.check(self._lib.sn_comm_init(self._h, int(world), int(rank), ctypes.c_char_p(bytes(unique_id))))
+        self.comm_world, self.comm_rank = int(world), int(rank)
 
     def allgather_f32_dev(self, local_dev, n_local, global_dev):
         _lib.check(self._lib.sn_allgather_f32_dev(self._h, local_dev, int(n_local), global_dev))
+
+    def allgather_f32_dev_overlap(self, local_dev, n_local, global_dev, slot):
+        """The all-gather on the context's communication stream, behind the kernels submitted so far and overlapping the ones submitted next;
+        `comm_wait(slot)` orders the kernel stream behind it again (before the two buffers are reused)."""
+        _lib.check(self._lib.sn_allgather_f32_dev_overlap(self._h, local_dev, int(n_local), global_dev, int(slot)))
+
+    def comm_wait(self, slot):
+        _lib.check(self._lib.sn_comm_wait(self._h, int(slot)))
+
+    def allgatherv_bytes(self, blob):
+        """Variable-length all-gather of one byte string per rank through the library's RCCL binding (sn_allgatherv_bytes_dev): `blob` (np.uint8, any
+        length incl. 0) -> list of `world` np.uint8 arrays in rank order. The payloads travel device to device over xGMI; only this rank's blob goes
+        up and the gathered bytes come down."""
+        world = getattr(self, "comm_world", 0)
+        if not world:
+            raise _lib.SurfaceNetHipError("allgatherv_bytes: comm_init has not been called on this context")
+        blob = np.ascontiguousarray(np.asarray(blob, dtype=np.uint8).reshape(-1))
+        d_local = self.upload(blob) if blob.size else None
+        counts = (ctypes.c_ulonglong * world)()
+        cap = max(64, 2 * world * max(int(blob.size), 1))
+        try:
+            while True:
+                d_all = self.dev_alloc(cap)
+                rc = self._lib.sn_allgatherv_bytes_dev(self._h, d_local, int(blob.size), d_all, cap, counts)
+                total = int(sum(counts))
+                if rc != 0 and total > cap:          # the ranks' contributions were larger than guessed: the counts are filled in, retry once
+                    self.dev_free(d_all)
+                    cap = total
+                    continue
+                _lib.check(rc)
+                out = np.empty((total,), dtype=np.uint8)
+                if total:
+                    self.d2h(out, d_all)
+                self.dev_free(d_all)
+                break
+        finally:
+            if d_local is not None:
+                self.dev_free(d_local)
+        ends = np.cumsum([int(c) for c in counts])
+        return [out[e - int(c): e] for c, e in zip(counts, ends)]
 
     # ---- measurement --------------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -580,6 +580,9 @@ void sn_destroy(sn_ctx *c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->marks) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
+    for (auto e : c->comm_ev) if (e) (void)hipEventDestroy(e);
+    if (c->comm_fork) (void)hipEventDestroy(c->comm_fork);
     for (void *p : c->owned) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -610,6 +613,7 @@ void *sn_stream(sn_ctx *c) { return c ? (void *)c->stream : nullptr; }
 static int sync_check(sn_ctx *c)
 {
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->comm_stream) HIPCHK(hipStreamSynchronize(c->comm_stream));
     if (c->d_num) {
         unsigned st = 0;
         HIPCHK(hipMemcpy(&st, c->d_num, sizeof st, hipMemcpyDeviceToHost));
@@ -1154,6 +1158,86 @@ int sn_allgather_f32_dev(sn_ctx *c, const float *local_dev, size_t n_local, floa
     ProfScope ps(c, "rccl_allgather", 0, (double)n_local * 4.0 * c->comm_world);
     const int e = g_rccl.AllGather(local_dev, global_dev, n_local, /*ncclFloat32*/ 7, c->rccl_comm, c->stream);
     if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather: %s", rccl_err(e));
+    return SN_OK;
+}
+
+// The same collective on the context's COMM stream, ordered behind everything submitted to the kernel stream so far, so that it overlaps the
+// kernels submitted next (the all-gather of batch i runs under the CVC + CNN of batch i + 1). `slot` (0..7) names the completion event:
+// sn_comm_wait(ctx, slot) makes the kernel stream wait for that collective - call it before local_dev / global_dev are written again.
+// sn_synchronize waits for both streams.
+int sn_allgather_f32_dev_overlap(sn_ctx *c, const float *local_dev, size_t n_local, float *global_dev, int slot)
+{
+    if (!c || !local_dev || !global_dev) return fail(SN_ERR_ARG, "null argument");
+    if (slot < 0 || slot >= 8) return fail(SN_ERR_ARG, "sn_allgather_f32_dev_overlap: slot must be 0..7");
+    if (!c->rccl_comm) return fail(SN_ERR_STATE, "sn_comm_init has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->comm_stream) HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    if (!c->comm_fork) HIPCHK(hipEventCreateWithFlags(&c->comm_fork, hipEventDisableTiming));
+    if (!c->comm_ev[slot]) HIPCHK(hipEventCreateWithFlags(&c->comm_ev[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->comm_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->comm_fork, 0));
+    const int e = g_rccl.AllGather(local_dev, global_dev, n_local, /*ncclFloat32*/ 7, c->rccl_comm, c->comm_stream);
+    if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather: %s", rccl_err(e));
+    HIPCHK(hipEventRecord(c->comm_ev[slot], c->comm_stream));
+    return SN_OK;
+}
+
+int sn_comm_wait(sn_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= 8) return fail(SN_ERR_ARG, "sn_comm_wait: slot must be 0..7");
+    if (!c->comm_ev[slot]) return SN_OK;                       // nothing was ever issued under this slot
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->comm_ev[slot], 0));
+    return SN_OK;
+}
+
+// Variable-length all-gather of bytes ("gather sparse voxels ... counts then all-gather-v"): every rank contributes n_local bytes
+// (device memory; n_local may be 0 and may differ from rank to rank), global_dev receives the contributions back to back in rank order, counts[r]
+// (host, `world` entries) their sizes. Two RCCL all-gathers on the context's stream - the 8-byte counts, then the payloads padded to the largest -
+// and one device-to-device copy per rank that closes the gaps. Synchronous (the host needs the counts to size the second step); returns
+// SN_ERR_ARG when global_cap bytes cannot hold the total, with counts[] filled so that the caller can retry with a larger buffer.
+int sn_allgatherv_bytes_dev(sn_ctx *c, const void *local_dev, size_t n_local, void *global_dev, size_t global_cap, unsigned long long *counts)
+{
+    if (!c || !counts || (n_local && !local_dev)) return fail(SN_ERR_ARG, "null argument");
+    if (!c->rccl_comm) return fail(SN_ERR_STATE, "sn_comm_init has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    const int W = c->comm_world;
+    auto need_stage = [&](size_t bytes) -> int {
+        if (bytes <= c->comm_stage_cap) return SN_OK;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->comm_stage) { dev_free_owned(c, c->comm_stage); c->comm_stage = nullptr; c->comm_stage_cap = 0; }
+        int rc = dev_alloc(c, &c->comm_stage, bytes);
+        if (rc != SN_OK) return rc;
+        c->comm_stage_cap = bytes;
+        return SN_OK;
+    };
+    int rc = need_stage((size_t)(W + 1) * 8);
+    if (rc != SN_OK) return rc;
+    const unsigned long long mine = n_local;
+    HIPCHK(hipMemcpyAsync(c->comm_stage + (size_t)W * 8, &mine, 8, hipMemcpyHostToDevice, c->stream));
+    int e = g_rccl.AllGather(c->comm_stage + (size_t)W * 8, c->comm_stage, 8, /*ncclUint8*/ 1, c->rccl_comm, c->stream);
+    if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather (counts): %s", rccl_err(e));
+    HIPCHK(hipMemcpyAsync(counts, c->comm_stage, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long total = 0, cap = 0;
+    for (int r = 0; r < W; ++r) { total += counts[r]; cap = std::max(cap, counts[r]); }
+    if (total > global_cap) return fail(SN_ERR_ARG, "sn_allgatherv_bytes_dev: %llu bytes gathered, the destination holds %zu", total, global_cap);
+    if (total == 0) return SN_OK;
+    if (!global_dev) return fail(SN_ERR_ARG, "null destination");
+    cap = (cap + 15) & ~15ull;
+    rc = need_stage((size_t)(W + 1) * cap);                      // [W padded payloads | this rank's padded payload]
+    if (rc != SN_OK) return rc;
+    unsigned char *mine_pad = c->comm_stage + (size_t)W * cap;
+    if (n_local) HIPCHK(hipMemcpyAsync(mine_pad, local_dev, n_local, hipMemcpyDeviceToDevice, c->stream));
+    ProfScope ps(c, "rccl_allgatherv", 0, (double)cap * W);
+    e = g_rccl.AllGather(mine_pad, c->comm_stage, cap, /*ncclUint8*/ 1, c->rccl_comm, c->stream);
+    if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather (payload): %s", rccl_err(e));
+    size_t off = 0;
+    for (int r = 0; r < W; ++r) {
+        if (counts[r]) HIPCHK(hipMemcpyAsync(static_cast<unsigned char *>(global_dev) + off, c->comm_stage + (size_t)r * cap, counts[r], hipMemcpyDeviceToDevice, c->stream));
+        off += counts[r];
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
     return SN_OK;
 }
 

@@ -91,6 +91,10 @@ struct sn_ctx {
     float *w3 = nullptr; float scale3 = 0, shift3 = 0;
     void *zero_page = nullptr; int num_cus = 256;
     void *rccl_comm = nullptr; int comm_world = 0, comm_rank = 0;   // RCCL communicator (lazy dlopen of librccl)
+    hipStream_t comm_stream = nullptr;                               // collectives that overlap the kernels (sn_allgather_f32_dev_overlap)
+    hipEvent_t comm_ev[8] = {};                                      // ... their completion, per caller slot; comm_fork: "the kernels so far are done"
+    hipEvent_t comm_fork = nullptr;
+    unsigned char *comm_stage = nullptr; size_t comm_stage_cap = 0;  // sn_allgatherv_bytes_dev: counts + padded payloads of all ranks
     float *relw_W1 = nullptr, *relw_scale = nullptr, *relw_shift = nullptr, *relw_w2 = nullptr; float relw_b2 = 0;
     // activation workspace (channels-last fp16)
     _Float16 *x0 = nullptr, *a1 = nullptr, *b1 = nullptr, *cat = nullptr, *p1 = nullptr, *a2 = nullptr, *b2 = nullptr,

@@ -312,7 +312,16 @@ def scene_select(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N
     if N_cubes == 0:           # an empty shard (more ranks than cubes): the projections below cannot reshape zero points
         return dict(patches_embedding=np.zeros((0, N_views, D_embedding), np.float32), inScope_cubes_vs_views=np.zeros((0, N_views), bool),
                     dissimilarity=np.zeros((0, len(viewPairs)), np.float32), validCubes=np.zeros((0,), bool))
-    runtime.prefer_cube_D(cube_D if ctx is None else ctx.cube_D)    # the projections / early rejection below use the scene's own context
+    with runtime.scene_context(ctx=ctx, cube_D=cube_D):           # the projections / early rejection below run in the scene's own context
+        return _scene_select_body(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, N_vp, N_views, N_cubes, viewPairs, patch2embedding_fn,
+                                  embeddingPair2simil_fn, viewPair_relativeImpt_fn, patches_mean_bgr, batchSize_similNet_patch2embedding,
+                                  batchSize_similNet_embeddingPair2simil, batchSize_viewPair_w, weighted_fusion, D_embedding, patchSize, lap)
+
+
+def _scene_select_body(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, N_vp, N_views, N_cubes, viewPairs, patch2embedding_fn, embeddingPair2simil_fn,
+                       viewPair_relativeImpt_fn, patches_mean_bgr, batchSize_similNet_patch2embedding, batchSize_similNet_embeddingPair2simil,
+                       batchSize_viewPair_w, weighted_fusion, D_embedding, patchSize, lap):
+    from . import camera, earlyRejection, viewPairSelection
     # main_reconstruct.py:67-71
     img_h_cubesCorner, img_w_cubesCorner = camera.perspectiveProj_cubesCorner(projection_M=cameraPOs_np, cube_xyz_min=cubes_param_np['xyz'],
                                                                               cube_D_mm=cube_D_mm, return_int_hw=False, return_depth=False)
@@ -390,39 +399,27 @@ _SELECT_KEYS = ("patch2embedding_fn", "embeddingPair2simil_fn", "viewPair_relati
 _LOOP_KEYS = ("cube_Dcenter", "batchSize_nViewPair_SurfaceNet", "min_prob", "tau", "gamma")
 
 
-def _scene_args(args, kwargs):
-    """reconstruct_scene's positional tail (patch2embedding_fn, embeddingPair2simil_fn, viewPair_relativeImpt_fn, cube_Dcenter, patches_mean_bgr)
-    and keywords -> (keywords of scene_select, keywords of scene_cube_loop)."""
-    names = ("patch2embedding_fn", "embeddingPair2simil_fn", "viewPair_relativeImpt_fn", "cube_Dcenter", "patches_mean_bgr")
-    if len(args) > len(names):
-        raise TypeError("too many positional arguments")
-    kw = dict(zip(names, args))
-    for k, v in kwargs.items():
-        if k in kw:
-            raise TypeError("%s given twice" % k)
-        kw[k] = v
-    unknown = set(kw) - set(_SELECT_KEYS) - set(_LOOP_KEYS) - {"ctx", "timings"}
-    if unknown:
-        raise TypeError("unexpected arguments %s" % sorted(unknown))
-    sel = {k: kw[k] for k in _SELECT_KEYS if k in kw}
-    loop = {k: kw[k] for k in _LOOP_KEYS if k in kw}
+def _split_scene_kw(kw):
+    """One dict of reconstruct_scene's named arguments -> (keywords of scene_select, keywords of scene_cube_loop)."""
+    sel = {k: kw[k] for k in _SELECT_KEYS}
+    loop = {k: kw[k] for k in _LOOP_KEYS}
     for d in (sel, loop):
         d["ctx"], d["timings"] = kw.get("ctx"), kw.get("timings")
     return sel, loop
 
 
-def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, *args, **kwargs):
+def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, patch2embedding_fn, embeddingPair2simil_fn,
+                      viewPair_relativeImpt_fn, cube_Dcenter, patches_mean_bgr, batchSize_similNet_patch2embedding=100,
+                      batchSize_similNet_embeddingPair2simil=100000, batchSize_viewPair_w=100000, batchSize_nViewPair_SurfaceNet=None,
+                      weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64, ctx=None, timings=None):
     """The body of main_reconstruct.reconstruction() between file input and PLY output (main_reconstruct.py:67-173):
     corner / centre projections -> early rejection (similarityNet) -> view-pair selection (relative-weight MLP) ->
     per batch: CVC, SurfaceNet, fusion, voxel colours, ray pooling, dense2sparse -> thinning masks  (= `scene_select` + `scene_cube_loop`).
-    Arguments after N_viewPairs4inference: patch2embedding_fn, embeddingPair2simil_fn, viewPair_relativeImpt_fn (the callables of
-    similarityNet.similarityNet_inference / SurfaceNet.SurfaceNet_inference; their weights are bound in `runtime`), cube_Dcenter,
-    patches_mean_bgr, then keywords: batchSize_similNet_patch2embedding=100, batchSize_similNet_embeddingPair2simil=100000,
-    batchSize_viewPair_w=100000, batchSize_nViewPair_SurfaceNet=None, weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8,
-    D_embedding=128, patchSize=64, ctx=None, timings=None (a dict that receives the wall seconds of every stage).
-    Returns a dict with the reference's variable names. Not included (out of scope): image / camera readers, cube tiling,
-    cross-cube denoising, PLY / npz writers."""
-    sel_kw, loop_kw = _scene_args(args, kwargs)
+    patch2embedding_fn, embeddingPair2simil_fn, viewPair_relativeImpt_fn: the callables of similarityNet.similarityNet_inference /
+    SurfaceNet.SurfaceNet_inference (their weights are bound in `runtime`); `timings`: a dict that receives the wall seconds of every stage.
+    A missing argument fails here, before any stage has run. Returns a dict with the reference's variable names. Not included (SURVEY §2.1,
+    out of scope): image / camera readers, cube tiling, cross-cube denoising, PLY / npz writers."""
+    sel_kw, loop_kw = _split_scene_kw(locals())
     out = scene_select(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, **sel_kw)
     valid = out["validCubes"]
     if not valid.any():
@@ -433,9 +430,13 @@ def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube
     return out
 
 
-def _allgather_bytes(blob, group=None, device=None):
-    """All-gather of one variable-length byte string per rank (np.uint8 1-D): lengths first, then one padded buffer. `device`:
-    where the collective runs (None = CPU tensors for gloo; a CUDA device for RCCL)."""
+def _allgather_bytes(blob, group=None, device=None, ctx=None):
+    """All-gather of one variable-length byte string per rank (np.uint8 1-D): lengths first, then one padded buffer. `ctx`: a Context whose
+    own RCCL communicator is up (`comm_init`) - the exchange then runs through the C ABI (`sn_allgatherv_bytes_dev`: device to device over
+    xGMI on the context's stream) and torch.distributed is not touched. Otherwise `device` says where the torch collective runs (None =
+    CPU tensors for gloo; a CUDA device for RCCL)."""
+    if ctx is not None and getattr(ctx, "comm_world", 0):
+        return ctx.allgatherv_bytes(blob)
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -451,17 +452,16 @@ def _allgather_bytes(blob, group=None, device=None):
     return [allb[r * cap: r * cap + int(sizes[r])] for r in range(world)]
 
 
-def _exchange(stage, make_blob, group=None, device=None):
+def _exchange(stage, make_blob, group=None, device=None, ctx=None):
     """Runs `make_blob()` (this rank's stage work -> np.uint8 payload) and all-gathers the payloads. A rank whose work raised does NOT
     leave the others blocked in the collective: every payload is prefixed with a status byte, the exception text travels in its place and
     every rank raises the same RuntimeError after the exchange."""
-    import torch.distributed as dist
     try:
         payload, err = make_blob(), None
     except Exception as e:              # noqa: BLE001 - whatever the stage raised must reach the other ranks as a message, not a hang
         payload, err = np.frombuffer(("%s: %s" % (type(e).__name__, e)).encode("utf-8", "replace"), dtype=np.uint8), e
     blob = np.concatenate([np.asarray([0 if err is None else 1], np.uint8), np.asarray(payload, np.uint8).reshape(-1)])
-    parts = _allgather_bytes(blob, group=group, device=device)
+    parts = _allgather_bytes(blob, group=group, device=device, ctx=ctx)
     failed = [(r, bytes(b[1:]).decode("utf-8", "replace")) for r, b in enumerate(parts) if b[0] != 0]
     if failed:
         msg = "; ".join("rank %d: %s" % f for f in failed)
@@ -519,8 +519,13 @@ def _merge_lists(blobs):
     return out
 
 
-def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, cube_D_mm=None, cube_D=None, N_viewPairs4inference=None, *args, **kwargs):
-    """`reconstruct_scene` over the ranks of a torch.distributed process group (one process per GPU; weights / images / cameras replicated).
+def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, cube_D_mm=None, cube_D=None, N_viewPairs4inference=None, patch2embedding_fn=None,
+                              embeddingPair2simil_fn=None, viewPair_relativeImpt_fn=None, cube_Dcenter=None, patches_mean_bgr=None,
+                              batchSize_similNet_patch2embedding=100, batchSize_similNet_embeddingPair2simil=100000, batchSize_viewPair_w=100000,
+                              batchSize_nViewPair_SurfaceNet=None, weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64,
+                              ctx=None, timings=None, group=None, comm_device=None, comm="auto", world=None, rank=None, select_fn=None, loop_fn=None,
+                              gather_intermediates=False):
+    """`reconstruct_scene` over the ranks of a job (one process per GPU; weights / images / cameras replicated).
 
     Stage 1 - early rejection and view-pair selection (`scene_select`) - is sharded by RAW cube range: its cost is per cube (V patches each),
     so contiguous ranges of the cube table balance it. Then ONE exchange of what stage 2 needs - the validCubes bits (1 bit per cube), the
@@ -530,20 +535,38 @@ def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, cube_D_
     would leave most of the loop on a few ranks. A second exchange of the packed sparse lists (9 B per kept voxel) rebuilds on every rank
     the dict `reconstruct_scene` returns (rank order = cube order). No data-path collective inside either stage.
 
-    Keywords beside reconstruct_scene's: `group`, `comm_device` (None: CPU tensors, e.g. gloo; a CUDA device for RCCL), `select_fn` / `loop_fn`
-    (stand-ins for the two stages, tests), `gather_intermediates` (False: the per-cube embeddings / dissimilarities - 25 KB per cube at 49
-    views, which no later stage needs - stay on the rank that computed them and the returned dict holds None for them).
+    The exchange (`comm`): "native" - the C ABI's own variable-length all-gather (`sn_allgatherv_bytes_dev`: RCCL on the context's stream, device
+    to device over xGMI) on `ctx`, whose communicator the caller has set up (`ctx.comm_init`; `world` / `rank` then default to the context's and
+    torch.distributed is not imported); "torch" - torch.distributed on `group` (`comm_device` None: CPU tensors, e.g. gloo; a CUDA device for
+    RCCL); "auto": native when `ctx` has a communicator, else torch. `select_fn` / `loop_fn`: stand-ins for the two stages (tests).
+    `gather_intermediates` False: the per-cube embeddings / dissimilarities (25 KB per cube at 49 views; no later stage needs them) are NOT
+    exchanged - the returned dict holds None under those keys (unlike `reconstruct_scene`'s, which holds the arrays) and this rank's own rows
+    under `local_select` (a dict with the three arrays) and `local_range` = (lo, hi) of the raw cube table.
     A rank that raises inside a stage makes every rank raise after the next exchange (never a hang). The returned dict also carries
-    `cubes_per_rank` = [(raw cubes, valid cubes in the loop), ...]."""
-    import torch.distributed as dist
-    group, comm_device = kwargs.pop("group", None), kwargs.pop("comm_device", None)
-    select_fn, loop_fn = kwargs.pop("select_fn", None), kwargs.pop("loop_fn", None)
-    gather_intermediates = bool(kwargs.pop("gather_intermediates", False))
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    `cubes_per_rank` = [(raw cubes, valid cubes in the loop), ...]. Missing stage arguments fail before any work or exchange."""
+    native = comm == "native" or (comm == "auto" and ctx is not None and getattr(ctx, "comm_world", 0))
+    if native:
+        if ctx is None or not getattr(ctx, "comm_world", 0):
+            raise ValueError("comm='native' needs a ctx whose communicator is initialised (ctx.comm_init)")
+        world, rank = (ctx.comm_world if world is None else int(world)), (ctx.comm_rank if rank is None else int(rank))
+    else:
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    xctx = ctx if native else None
+    gather_intermediates = bool(gather_intermediates)
+    if select_fn is None or loop_fn is None:
+        need = dict(cube_D_mm=cube_D_mm, cube_D=cube_D, N_viewPairs4inference=N_viewPairs4inference)
+        if select_fn is None:
+            need.update(patch2embedding_fn=patch2embedding_fn, embeddingPair2simil_fn=embeddingPair2simil_fn, viewPair_relativeImpt_fn=viewPair_relativeImpt_fn,
+                        patches_mean_bgr=patches_mean_bgr)
+        if loop_fn is None:
+            need.update(cube_Dcenter=cube_Dcenter)
+        missing = sorted(k for k, v in need.items() if v is None)
+        if missing:
+            raise TypeError("reconstruct_scene_sharded: missing argument(s) %s" % ", ".join(missing))
+        sel_kw, loop_kw = _split_scene_kw(locals())
     N_cubes = len(cubes_param_np)
     lo, hi = shard_bounds(N_cubes, world, rank)
-    if select_fn is None or loop_fn is None:
-        sel_kw, loop_kw = _scene_args(args, kwargs)
     local = {}
 
     def stage1():
@@ -558,12 +581,13 @@ def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, cube_D_
             arrs.update({k: np.asarray(sel[k]) for k in _SELECT_ROWS})
         return _npz_bytes(arrs)
 
-    parts = [_npz_load(b) for b in _exchange("early rejection / view-pair selection", stage1, group=group, device=comm_device)]
+    parts = [_npz_load(b) for b in _exchange("early rejection / view-pair selection", stage1, group=group, device=comm_device, ctx=xctx)]
     validCubes = np.concatenate([np.unpackbits(p["bits"])[: int(p["n"][0])].astype(bool) for p in parts]) if N_cubes else np.zeros((0,), bool)
     have = [p for p in parts if "vp" in p.files]
     out = dict(validCubes=validCubes, viewPairs4Reconstr=None, w_viewPairs4Reconstr=None)
     for k in _SELECT_ROWS:
         out[k] = np.concatenate([p[k] for p in parts], axis=0) if gather_intermediates else None
+    out["local_select"], out["local_range"] = {k: local.get(k) for k in _SELECT_ROWS}, (lo, hi)
     n_valid = int(validCubes.sum())
     per_rank_raw = [int(p["n"][0]) for p in parts]
     if n_valid == 0:
@@ -580,6 +604,6 @@ def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, cube_D_
                scene_cube_loop(images_list, cameraPOs_np, valid_rows[vlo:vhi], vp[vlo:vhi], w[vlo:vhi], cube_D, N_viewPairs4inference, **loop_kw))
         return _pack_lists(res)
 
-    out.update(_merge_lists(_exchange("cube loop", stage2, group=group, device=comm_device)))
+    out.update(_merge_lists(_exchange("cube loop", stage2, group=group, device=comm_device, ctx=xctx)))
     out["cubes_per_rank"] = [(per_rank_raw[r], shard_bounds(n_valid, world, r)[1] - shard_bounds(n_valid, world, r)[0]) for r in range(world)]
     return out

@@ -48,9 +48,37 @@ def prefer_cube_D(cube_D):
     _preferred_cube_D = None if cube_D is None else int(cube_D)
 
 
+_pinned_ctx = None
+
+
+class scene_context(object):
+    """`with runtime.scene_context(ctx=..., cube_D=...):` - for the duration of the block the cube-size independent work of the drop-in modules
+    (projections, patch cropping, the similarityNet) runs in the caller's own `ctx` (also one built by hand, which `context_for` does not know)
+    or, without one, in the context of `cube_D`. The previous setting - also `prefer_cube_D`'s - is restored on exit, so a scene does not leave
+    its choice behind for unrelated calls of the same process."""
+
+    def __init__(self, ctx=None, cube_D=None):
+        self.ctx, self.cube_D = ctx, cube_D
+
+    def __enter__(self):
+        global _pinned_ctx, _preferred_cube_D
+        self._saved = (_pinned_ctx, _preferred_cube_D)
+        _pinned_ctx = self.ctx
+        if self.ctx is None and self.cube_D is not None:
+            _preferred_cube_D = int(self.cube_D)
+        return self
+
+    def __exit__(self, *exc):
+        global _pinned_ctx, _preferred_cube_D
+        _pinned_ctx, _preferred_cube_D = self._saved
+        return False
+
+
 def any_context():
-    """A context for work that does not depend on cube_D (projections, similarityNet, patch cropping): the preferred size's context
-    (prefer_cube_D), else any live one, else a new one of the smaller size."""
+    """A context for work that does not depend on cube_D (projections, similarityNet, patch cropping): the one a running scene pinned
+    (scene_context), else the preferred size's (prefer_cube_D), else any live one, else a new one of the smaller size."""
+    if _pinned_ctx is not None:
+        return _pinned_ctx
     if _preferred_cube_D is not None:
         return context_for(_preferred_cube_D)
     for ctx in _contexts.values():

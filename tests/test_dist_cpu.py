@@ -239,6 +239,53 @@ def test_sharded_scene_balances_the_valid_list_gloo():
     for rank, full, counts in _run_scene_ranks(9, "lean", 37500):
         _same_scene(full, want, intermediates=False)
         assert full["patches_embedding"] is None and full["dissimilarity"] is None
+        # ... and the rank's own rows stay available under local_select / local_range
+        lo, hi = full["local_range"]
+        assert (lo, hi) == ((0, 5) if rank == 0 else (5, 9))
+        for k in ("patches_embedding", "inScope_cubes_vs_views", "dissimilarity"):
+            assert np.array_equal(full["local_select"][k], want[k][lo:hi]), k
+
+
+def test_sharded_scene_checks_its_arguments_before_any_work():
+    """The stage arguments are named parameters: one that is missing fails at the call, not after the early-rejection stage and its collective
+    (ADVICE r3); comm='native' without a context that holds a communicator fails likewise, without importing torch.distributed."""
+    from surfacenet_amd import reconstruct
+    import inspect
+    sig = inspect.signature(reconstruct.reconstruct_scene_sharded)
+    assert "cube_Dcenter" in sig.parameters and "patch2embedding_fn" in sig.parameters and "comm" in sig.parameters
+    assert "cube_Dcenter" in inspect.signature(reconstruct.reconstruct_scene).parameters
+    with pytest.raises(ValueError, match="comm='native' needs a ctx"):
+        reconstruct.reconstruct_scene_sharded([], np.zeros((3, 3, 4)), _scene_cubes(3), comm="native")
+
+    class _Comm(object):                  # a context whose communicator is "up": the argument check comes before any exchange
+        comm_world, comm_rank = 1, 0
+
+        def allgatherv_bytes(self, blob):
+            raise AssertionError("no exchange may start before the arguments are checked")
+    with pytest.raises(TypeError, match="missing argument.*cube_Dcenter"):
+        reconstruct.reconstruct_scene_sharded([], np.zeros((3, 3, 4)), _scene_cubes(3), 12.8, 32, 2, lambda *a: None, lambda *a: None, lambda *a: None,
+                                              patches_mean_bgr=np.zeros(3, np.float32), ctx=_Comm(), comm="native")
+
+
+def test_sharded_scene_native_exchange_interface():
+    """The scene's two exchanges through a context's own all-gather-v (`ctx.allgatherv_bytes` = sn_allgatherv_bytes_dev on a GPU box) instead of
+    torch.distributed: same packing, same result. Here a one-rank stand-in that returns the blob it is given (world 1); the GPU suite runs
+    the real call (tests/test_gpu_pipeline.py)."""
+    from surfacenet_amd import reconstruct
+
+    class _Loopback(object):
+        comm_world, comm_rank = 1, 0
+        calls = 0
+
+        def allgatherv_bytes(self, blob):
+            self.calls += 1
+            return [np.array(blob, dtype=np.uint8, copy=True)]
+    ctx = _Loopback()
+    want = _fake_scene([], None, _scene_cubes(11))
+    got = reconstruct.reconstruct_scene_sharded([], np.zeros((3, 3, 4)), _scene_cubes(11), select_fn=lambda i, P, c: _fake_select(i, P, c, None),
+                                                loop_fn=_fake_loop, gather_intermediates=True, ctx=ctx, comm="native")
+    _same_scene(got, want)
+    assert ctx.calls == 2 and got["cubes_per_rank"] == [(11, int(want["validCubes"].sum()))]
 
 
 def test_sharded_scene_failure_on_one_rank_raises_everywhere_gloo():

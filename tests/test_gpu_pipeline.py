@@ -152,6 +152,45 @@ def test_sharded_scene_two_processes_equals_single_process(gpu_required):
         assert full["cubes_per_rank"] == [(6, n_valid - n_valid // 2), (6, n_valid // 2)]        # the loop is cut over the valid list, to within one cube
 
 
+def test_native_allgatherv_and_native_sharded_scene_one_rank(gpu_required):
+    """SURVEY §8(e) "counts then all-gather-v" through the C ABI (sn_allgatherv_bytes_dev: RCCL on the context's stream) with a one-rank
+    communicator - all this box offers: blobs of assorted lengths (0, 1, unaligned, 1 MB) come back unchanged, and reconstruct_scene_sharded with
+    comm='native' (both exchanges through the library, torch.distributed never imported) equals the single-process reconstruct_scene; also the
+    overlapped f32 all-gather (sn_allgather_f32_dev_overlap / sn_comm_wait) against the in-order one."""
+    import test_dist_cpu
+    from surfacenet_amd import Context, SurfaceNet, reconstruct, runtime, similarityNet
+    inp = _pipeline_inputs()
+    want = _run_scene(inp, sharded=False)
+    runtime.reset()
+    try:
+        p2e, pair_fn = similarityNet.similarityNet_inference(None, (64, 64), param_values=inp["simil_values"])
+        relw_fn, _ = SurfaceNet.SurfaceNet_inference(inp["N_vp"], None, None, cube_D=inp["cube_D"], param_values=inp["net_values"])
+        ctx = runtime.context_for(inp["cube_D"])
+        ctx.comm_init(1, 0, Context.comm_unique_id())
+        rs = np.random.RandomState(5)
+        for size in (0, 1, 17, 4099, 1 << 20):
+            blob = rs.randint(0, 256, size).astype(np.uint8)
+            got = ctx.allgatherv_bytes(blob)
+            assert len(got) == 1 and got[0].dtype == np.uint8 and np.array_equal(got[0], blob)
+        a = rs.rand(1 << 16).astype(np.float32)
+        d_a, d_g1, d_g2 = ctx.upload(a), ctx.dev_alloc(a.nbytes), ctx.dev_alloc(a.nbytes)
+        ctx.allgather_f32_dev(d_a, a.size, d_g1)
+        ctx.allgather_f32_dev_overlap(d_a, a.size, d_g2, 3)
+        ctx.comm_wait(3); ctx.comm_wait(4)                          # (slot 4 was never used: a no-op)
+        g1, g2 = np.empty_like(a), np.empty_like(a)
+        ctx.d2h(g1, d_g1); ctx.d2h(g2, d_g2)
+        assert np.array_equal(g1, a) and np.array_equal(g2, a)
+        for p in (d_a, d_g1, d_g2):
+            ctx.dev_free(p)
+        res = reconstruct.reconstruct_scene_sharded(inp["imgs"], inp["P"], inp["cubes"], inp["cube_D_mm"], inp["cube_D"], inp["N_vp"], p2e, pair_fn, relw_fn,
+                                                    cube_Dcenter=inp["Dc"], patches_mean_bgr=MEAN_BGR, batchSize_nViewPair_SurfaceNet=4, min_prob=0.5, tau=0.6,
+                                                    gamma=0.5, gather_intermediates=True, ctx=ctx, comm="native")
+        test_dist_cpu._same_scene(res, want)
+        assert res["cubes_per_rank"] == [(len(inp["cubes"]), int(want["validCubes"].sum()))]
+    finally:
+        runtime.reset()
+
+
 def test_marked_readback_sees_its_own_batch(gpu_required):
     """sn_mark / sn_memcpy_d2h_after (reconstruct.SparseLoop.run_many's readback): the copy waits for the work enqueued BEFORE the mark
     only - it returns the data as of the mark even when later work on the context's stream has already been enqueued to overwrite
