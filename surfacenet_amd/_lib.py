@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "sn_simil_load_weights", "sn_crop_patches", "sn_patch2embedding", "sn_crop_embed", "sn_embeddingpair2simil", "sn_embeddings2simil",
     "sn_project_points",
     "sn_comm_unique_id", "sn_comm_init", "sn_allgather_f32_dev", "sn_allgather_f32_dev_overlap", "sn_comm_wait", "sn_allgatherv_bytes_dev",
+    "sn_calibrate_dev", "sn_numeric_status",
     "sn_profile_enable", "sn_profile_count", "sn_profile_get", "sn_profile_reset",
 ]
 
@@ -33,6 +34,12 @@ class SurfaceNetHipError(RuntimeError):
 class SparseCfg(ctypes.Structure):
     _fields_ = [("min_prob", ctypes.c_float), ("rayPool_thresh", ctypes.c_int), ("enable_centerCrop", ctypes.c_int),
                 ("cube_Dcenter", ctypes.c_int), ("enable_rayPooling", ctypes.c_int)]
+
+
+class Calibration(ctypes.Structure):
+    _fields_ = [("s_act_before", ctypes.c_int), ("s_cat_before", ctypes.c_int), ("s_act", ctypes.c_int), ("s_cat", ctypes.c_int),
+                ("sat_act_before", ctypes.c_double), ("sat_cat_before", ctypes.c_double), ("sat_act", ctypes.c_double), ("sat_cat", ctypes.c_double),
+                ("max_act", ctypes.c_float), ("max_cat", ctypes.c_float)]
 
 
 class ParamDesc(ctypes.Structure):
@@ -98,6 +105,8 @@ def load():
         "sn_project_points": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
         "sn_comm_unique_id": (c_int, [ctypes.c_char_p]),
         "sn_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p]),
+        "sn_calibrate_dev": (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p]),
+        "sn_numeric_status": (c_int, [c_void_p, c_void_p, ctypes.c_char_p, c_int]),
         "sn_allgather_f32_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
         "sn_allgather_f32_dev_overlap": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
         "sn_comm_wait": (c_int, [c_void_p, c_int]),

@@ -327,6 +327,25 @@ class Context(object):
         _lib.check(self._lib.sn_dense2sparse_dev(self._h, n, n_vp, pairs_dev, xyz_dev, resol_dev, pred_dev, rgb_dev, ctypes.byref(cfg),
                                                  votes_ws_dev, offsets_dev, ijk_dev, pred16_dev, rgb_out_dev, votes_out_dev))
 
+    # ---- numerics of the 6-bit code planes (default mode) ---------------------------------------------------
+    def calibrate(self, n_samples, max_sat_fraction=1e-3):
+        """Data-driven premultipliers of the two code planes (sn_calibrate_dev): looks at the activations the LAST forward call left in the
+        workspace (`n_samples` of them - run `forward` / `cvc_forward` on a representative batch first) and sets each plane's exponent to the
+        largest one that saturates at most `max_sat_fraction` of the values. Returns a dict (exponents and saturated fractions before / after,
+        largest magnitudes). The setting holds until the next load_param_values / precision change."""
+        cal = _lib.Calibration()
+        _lib.check(self._lib.sn_calibrate_dev(self._h, int(n_samples), float(max_sat_fraction), ctypes.byref(cal)))
+        return {k: getattr(cal, k) for k, _ in _lib.Calibration._fields_}
+
+    def numeric_status(self):
+        """Warning-level numeric status: names of the layers whose stored outputs exceeded the range of their 6-bit code plane since the last
+        call (such a value loses its own correction term only; not an error). Clears the warning bits."""
+        bits = ctypes.c_uint(0)
+        names = ctypes.create_string_buffer(2048)
+        _lib.check(self._lib.sn_numeric_status(self._h, ctypes.byref(bits), names, 2048))
+        nm = [x for x in names.value.decode().split(",") if x]
+        return [nm[i] if i < len(nm) else "layer %d" % i for i in range(32) if bits.value & (1 << i)]
+
     # ---- multi-GPU exchange (RCCL, native; torch.distributed is not required) ---------------------------
     @staticmethod
     def comm_unique_id():

@@ -172,6 +172,9 @@ struct ConvArgs {
     int side_cs, side_coff, pool_cs, side_act;
     unsigned *status;         // numeric status word of the context (or nullptr): status_bit is OR-ed in when an output value is not
     unsigned status_bit;      // finite or exceeds the fp16 range its hi plane is stored in (|y| > 65504)
+    unsigned mx_sat_bits;     // != 0: the output tensor carries a 6-bit code plane; fp16 bits of the largest value its static premultiplier represents
+                              // (7.5 * 2^-s). A larger stored value saturates its code (only that element's correction term degrades): status[1] |= status_bit,
+                              // a WARNING the host can read (sn_numeric_status), never an error
     float scale3, shift3;
     long long wsplit_stride;  // halfs between channel splits in wpack
     long long in_lo_off, out_lo_off;
@@ -212,8 +215,12 @@ __device__ __forceinline__ void sn_track_acc(f32x2_t &c, const f32x4 &a)
     asm volatile("v_pk_fma_f32 %0, %1, 0, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "v"(lo));
     asm volatile("v_pk_fma_f32 %0, %1, 0, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "v"(hi));
 }
-__device__ __forceinline__ void sn_track_h2(unsigned &c, unsigned h2) { asm volatile("v_pk_fma_f16 %0, %1, 0, %0" : "+v"(c) : "v"(h2)); }
-__device__ __forceinline__ bool sn_tracked_bad(const f32x2_t &c, unsigned h) { return !(c.x == 0.f && c.y == 0.f) || (h & 0x7fff7fffu) != 0u; }
+// (round 4: the stored-value tracker is a packed MAX, same cost - every store epilogue stores non-negative values (ReLU / sigmoid / pooled ReLU), so the
+// largest stored half is +inf exactly when a value left the fp16 range, and the same register also says whether a value exceeded the range of the
+// 6-bit code plane its tensor carries: the saturation warning of ConvArgs::mx_sat_bits)
+__device__ __forceinline__ void sn_track_h2(unsigned &c, unsigned h2) { asm volatile("v_pk_max_f16 %0, %1, %0" : "+v"(c) : "v"(h2)); }
+__device__ __forceinline__ unsigned sn_tracked_max_bits(unsigned h) { const unsigned lo = h & 0x7fffu, hi = (h >> 16) & 0x7fffu; return lo > hi ? lo : hi; }   // fp16 bits of the largest stored value
+__device__ __forceinline__ bool sn_tracked_bad(const f32x2_t &c, unsigned h) { return !(c.x == 0.f && c.y == 0.f) || sn_tracked_max_bits(h) >= 0x7c00u; }
 
 // hi/lo split of an fp32 value into two fp16 (hi = rn(y), lo = rn(y - hi)); |y - hi - lo| <= 2^-22 |y|
 __device__ __forceinline__ void sn_split(float y, _Float16 &hi, _Float16 &lo)
@@ -2070,6 +2077,7 @@ conv3d_f16_mfma(ConvArgs a)
     if constexpr (PP && !SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }       // pairs with group 1's last compute segment
     bad |= sn_tracked_bad(trk_acc, trk_h);
     if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, a.status_bit);
+    if (a.status && a.mx_sat_bits != 0 && __builtin_amdgcn_ballot_w64(sn_tracked_max_bits(trk_h) > a.mx_sat_bits) != 0 && lane == 0) atomicOr(a.status + 1, a.status_bit);
     if constexpr (SN_TIMING) {
         if (a.status && lane == 0) {        // [2..9]: per layer-bit slot of 4 x u64: kernel cycles, vmcnt-wait cycles, barrier-wait cycles, pieces (summed over waves)
             unsigned long long *t = reinterpret_cast<unsigned long long *>(a.status + 2) + 4 * (31 - __builtin_clz(a.status_bit));

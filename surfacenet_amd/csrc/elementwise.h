@@ -241,6 +241,43 @@ __global__ void __launch_bounds__(256) upsample3_cat_tiled_kernel(const _Float16
     }
 }
 
+// Calibration scan (sn_calibrate_dev): how many of a tensor's stored fp16 values exceed the range of 6-bit codes under each candidate premultiplier.
+// hist[j], j = 0 .. kMxScanBins - 1: count of |v| > lim * 2^-(j - kMxScanBins / 2), lim = the code format's largest magnitude; hist[kMxScanBins] = count of
+// non-zero values, hist[kMxScanBins + 1] = fp16 bits of the largest magnitude. `halfs` is a multiple of 8 (8-channel groups).
+constexpr int kMxScanBins = 13;      // premultiplier exponents s = -6 .. +6
+static __global__ void __launch_bounds__(256) mx_scan_kernel(const _Float16 *t, long long halfs, float lim, unsigned long long *hist)
+{
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    unsigned cnt[kMxScanBins + 1], thr[kMxScanBins];
+#pragma unroll
+    for (int j = 0; j < kMxScanBins; ++j) {
+        const _Float16 h = (_Float16)ldexpf(lim, -(j - kMxScanBins / 2));
+        thr[j] = __builtin_bit_cast(unsigned short, h);       // (non-negative fp16 values order like their bit patterns)
+        cnt[j] = 0;
+    }
+    cnt[kMxScanBins] = 0;
+    unsigned mx = 0;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < halfs; i += (long long)gridDim.x * 256 * 8) {
+        const u16x8 v = *reinterpret_cast<const u16x8 *>(t + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned b = v[e] & 0x7fffu;
+            mx = b > mx ? b : mx;
+            cnt[kMxScanBins] += b != 0u;
+#pragma unroll
+            for (int j = 0; j < kMxScanBins; ++j) cnt[j] += b > thr[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= kMxScanBins; ++j) {
+        unsigned c = cnt[j];
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(hist + j, (unsigned long long)c);
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned m2 = __shfl_xor(mx, o); mx = m2 > mx ? m2 : mx; }
+    if ((threadIdx.x & 63) == 0) atomicMax(hist + kMxScanBins + 1, (unsigned long long)mx);
+}
+
 // unfused [n][n_vp][s3] f32, w [n][n_vp] -> fused [n][s3]; w == nullptr (n_vp == 1) copies.
 static __global__ void __launch_bounds__(256) fuse_kernel(const float *unfused, const float *w, float *fused, int n_vp, int s3, long long total)
 {

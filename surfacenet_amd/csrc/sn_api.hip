@@ -588,6 +588,16 @@ void sn_destroy(sn_ctx *c)
     delete c;
 }
 
+// the static premultipliers of the 6-bit code planes (mx_format.h); sn_calibrate_dev replaces them with measured ones until the next call of this
+static void reset_mx_exponents(sn_ctx *c)
+{
+    c->mx_act_e8 = kMxActE8; c->mx_cat_e8 = kMxCatE8;
+    if (c->mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0) {                                    // accuracy sweeps only (mx_format.h)
+        if (getenv("SN_MX_S_ACT")) c->mx_act_e8 = 127 - std::max(-8, std::min(8, atoi(getenv("SN_MX_S_ACT"))));
+        if (getenv("SN_MX_S_CAT")) c->mx_cat_e8 = 127 - std::max(-8, std::min(8, atoi(getenv("SN_MX_S_CAT"))));
+    }
+}
+
 int sn_set_precision(sn_ctx *c, int mode)
 {
     if (!c) return fail(SN_ERR_ARG, "null context");
@@ -598,11 +608,7 @@ int sn_set_precision(sn_ctx *c, int mode)
     c->split = mode == SN_PRECISION_F16X3_PURE ? 1 : mode;
     c->tail_m8 = mode == SN_PRECISION_F16X3 ? 2 : 0;
     if (mode == SN_PRECISION_F16X3 && getenv("SN_M8_TAIL")) c->tail_m8 = std::max(0, std::min(2, atoi(getenv("SN_M8_TAIL"))));   // A/B measurements only
-    c->mx_act_e8 = kMxActE8; c->mx_cat_e8 = kMxCatE8;
-    if (mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0) {                                       // accuracy sweeps only (mx_format.h)
-        if (getenv("SN_MX_S_ACT")) c->mx_act_e8 = 127 - std::max(-8, std::min(8, atoi(getenv("SN_MX_S_ACT"))));
-        if (getenv("SN_MX_S_CAT")) c->mx_cat_e8 = 127 - std::max(-8, std::min(8, atoi(getenv("SN_MX_S_CAT"))));
-    }
+    reset_mx_exponents(c);
     return SN_OK;
 }
 
@@ -643,6 +649,70 @@ int sn_synchronize(sn_ctx *c)
     return sync_check(c);
 }
 
+// Warning-level numeric status (ConvArgs::mx_sat_bits): layers whose stored outputs exceeded the range of their 6-bit code plane since the last call.
+int sn_numeric_status(sn_ctx *c, unsigned *saturated_bits, char *names, int names_cap)
+{
+    if (!c || !saturated_bits) return fail(SN_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned st = 0;
+    if (c->d_num) {
+        HIPCHK(hipMemcpy(&st, c->d_num + 1, sizeof st, hipMemcpyDeviceToHost));
+        if (st) HIPCHK(hipMemset(c->d_num + 1, 0, sizeof st));
+    }
+    *saturated_bits = st;
+    if (names && names_cap > 0) {
+        std::string all;
+        for (auto &n : c->num_names) all += n + ",";
+        snprintf(names, (size_t)names_cap, "%s", all.c_str());
+    }
+    return SN_OK;
+}
+
+// Data-driven premultipliers of the code planes (header). Scans the hi planes of the concat buffer and of merge_conv_a's output as the last
+// forward call left them.
+int sn_calibrate_dev(sn_ctx *c, int n_samples, double max_sat_fraction, sn_calibration *out)
+{
+    if (!c || !out) return fail(SN_ERR_ARG, "null argument");
+    if (!(c->split == 2 || (c->split == 1 && c->tail_m8 >= 2)) || SN_MX_FMT == 0)
+        return fail(SN_ERR_STATE, "sn_calibrate_dev: this precision mode stores no 6-bit code planes");
+    if (!c->cat || !c->ma || n_samples < 1 || n_samples > c->max_samples) return fail(SN_ERR_ARG, "sn_calibrate_dev: n_samples must be 1..max_samples, after a forward call");
+    if (!(max_sat_fraction >= 0.0 && max_sat_fraction < 1.0)) return fail(SN_ERR_ARG, "sn_calibrate_dev: max_sat_fraction must be in [0, 1)");
+    HIPCHK(hipSetDevice(c->device));
+    const long long vox = (long long)c->s * c->s * c->s;
+    const float lim = SN_MX_FMT == 2 ? 7.5f : 28.f;
+    TmpDev tmp;
+    unsigned long long *d_hist = tmp.get<unsigned long long>(2 * (kMxScanBins + 2));
+    if (!d_hist) return fail(SN_ERR_HIP, "out of device memory");
+    HIPCHK(hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * 2 * (kMxScanBins + 2), c->stream));
+    const _Float16 *tens[2] = {c->ma, c->cat};
+    const long long halfs[2] = {(long long)n_samples * vox * 104, (long long)n_samples * vox * 64};
+    for (int t = 0; t < 2; ++t)
+        hipLaunchKernelGGL(mx_scan_kernel, dim3((unsigned)std::min<long long>(2048, (halfs[t] / 8 + 255) / 256)), dim3(256), 0, c->stream, tens[t], halfs[t], lim,
+                           d_hist + t * (kMxScanBins + 2));
+    HIPCHK(hipGetLastError());
+    unsigned long long h[2][kMxScanBins + 2];
+    HIPCHK(hipMemcpyAsync(h, d_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int s_new[2];
+    double sat_new[2], sat_old[2];
+    const int s_old[2] = {127 - c->mx_act_e8, 127 - c->mx_cat_e8};
+    for (int t = 0; t < 2; ++t) {
+        const double nz = (double)std::max<unsigned long long>(h[t][kMxScanBins], 1);
+        auto frac = [&](int s) { const int j = std::max(0, std::min(kMxScanBins - 1, s + kMxScanBins / 2)); return (double)h[t][j] / nz; };
+        int s = -kMxScanBins / 2;
+        for (int cand = kMxScanBins / 2; cand >= -kMxScanBins / 2; --cand)
+            if (frac(cand) <= max_sat_fraction) { s = cand; break; }
+        s_new[t] = s; sat_new[t] = frac(s); sat_old[t] = frac(std::max(-kMxScanBins / 2, std::min(kMxScanBins / 2, s_old[t])));
+    }
+    auto f16_of = [](unsigned long long bits) { unsigned short b = (unsigned short)bits; _Float16 v; memcpy(&v, &b, 2); return (float)v; };
+    out->s_act_before = s_old[0]; out->s_cat_before = s_old[1]; out->s_act = s_new[0]; out->s_cat = s_new[1];
+    out->sat_act_before = sat_old[0]; out->sat_cat_before = sat_old[1]; out->sat_act = sat_new[0]; out->sat_cat = sat_new[1];
+    out->max_act = f16_of(h[0][kMxScanBins + 1]); out->max_cat = f16_of(h[1][kMxScanBins + 1]);
+    c->mx_act_e8 = 127 - s_new[0]; c->mx_cat_e8 = 127 - s_new[1];
+    return SN_OK;
+}
+
 int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_param_desc *descs, int n_params)
 {
     if (!c || !blob || !descs) return fail(SN_ERR_ARG, "null argument");
@@ -656,6 +726,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
             return fail(SN_ERR_ARG, "param %d: [offset, offset+size) outside the blob", i);
     }
     { int rcw = ensure_workspace(c); if (rcw != SN_OK) return rcw; }
+    reset_mx_exponents(c);      // (a calibration belongs to the weights it was measured with)
     // free previously loaded weights
     for (auto &kv : c->conv) { dev_free_owned(c, kv.second.wpack); dev_free_owned(c, kv.second.scale); dev_free_owned(c, kv.second.shift); dev_free_owned(c, kv.second.side_frag); }
     c->conv.clear();

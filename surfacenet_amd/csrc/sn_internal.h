@@ -271,6 +271,12 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
         size_t bit = it - c->num_names.begin();
         if (it == c->num_names.end() && c->num_names.size() < 31) c->num_names.push_back(L.name);
         a.status = c->d_num;
+        // saturation warning: only for tensors stored with a 6-bit code plane whose values are not bounded by construction (ReLU outputs)
+        if (EPI == EPI_STORE && (OSPLIT < 0 ? SPLIT : OSPLIT) == 2 && SN_MX_FMT != 0 && L.act == 0) {
+            const _Float16 lim = (_Float16)std::ldexp(SN_MX_FMT == 2 ? 7.5f : 28.f, a.mx_out_e8 - 127);
+            unsigned short bits; memcpy(&bits, &lim, 2);
+            a.mx_sat_bits = bits;
+        }
         a.status_bit = bit < 31 ? (1u << bit) : (1u << 31);
     }
     a.nslab = (int)L.slab_c8.size();

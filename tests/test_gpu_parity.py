@@ -87,7 +87,7 @@ TOL_X3P = 5e-5
 TOL_X3_EMU, RMS_X3_EMU = 1e-4, 0.8
 #   f16m8 (every layer: f16 main term + 6-bit MX correction terms; experimental, dominated by the default in speed and accuracy):
 #   vs fp64 within the north-star bar (observed 6e-5 .. 4e-4); vs its CPU model (which simplifies the fused side convolutions) < 4e-4 (observed 5e-5 .. 2.2e-4)
-TOL_M8, TOL_M8_EMU = 1e-3, 4e-4
+TOL_M8, TOL_M8_EMU = 6e-4, 4e-4   # f16m8 everywhere is an opt-in stress mode of the code format (measured 6e-5 .. 4e-4); asserted BELOW the 1e-3 bar
 
 
 def _net_case(s, n, n_vp, seed):
