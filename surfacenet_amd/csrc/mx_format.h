@@ -73,9 +73,14 @@ __device__ __forceinline__ void sn_mx6_units(const _Float16 (&h0)[4], const floa
         a[r] = h0[r]; a[4 + r] = (_Float16)lo0[r];
         b[r] = h1[r]; b[4 + r] = (_Float16)lo1[r];
     }
-    // elements 0..7 = a, 16..23 = b (-> bits 96..143 = dwords 3 and 4); the other 16 inputs are don't-cares (their codes are dropped): left
-    // undefined instead of zeroed, which cost 8 register moves per call
-    const mx_v32h v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, -1, -1, -1, -1, -1, -1, -1, -1, 8, 9, 10, 11, 12, 13, 14, 15, -1, -1, -1, -1, -1, -1, -1, -1);
+    // elements 0..7 = a, 16..23 = b (-> bits 96..143 = dwords 3 and 4); the other 16 inputs are don't-cares (their codes are dropped). Zeroing them
+    // cost 8 register moves per call; they are FROZEN unspecified values instead (__builtin_nondeterministic_value: whatever the registers hold,
+    // but a defined value to the optimiser - a poison operand would license it to fold the whole conversion away). No instruction.
+    typedef _Float16 mx_v16h __attribute__((ext_vector_type(16)));
+    const mx_v16h ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    mx_v16h dc0 = {};
+    const mx_v16h dc = __builtin_nondeterministic_value(dc0);
+    const mx_v32h v = __builtin_shufflevector(ab, dc, 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23, 8, 9, 10, 11, 12, 13, 14, 15, 24, 25, 26, 27, 28, 29, 30, 31);
     const mx_v6i c = sn_mx6_cvt(v, e8);
     w[0][0] = (unsigned)c[0]; w[0][1] = (unsigned)c[1];
     w[1][0] = (unsigned)c[3]; w[1][1] = (unsigned)c[4];

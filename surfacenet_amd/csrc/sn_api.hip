@@ -348,7 +348,7 @@ static int launch_up3(sn_ctx *c, Act s2, Act s3, Act s4, Act cat, int B, int Do,
 {
     const long long total = (long long)B * Do * Do * Do * 6;
     ProfScope ps(c, "side_op234_deconv", 0, (double)B * Do * Do * Do * 48 * 2.0 * (SPLIT ? 2 : 1));
-    static const bool per_voxel = getenv("SN_UPSAMPLE_PER_VOXEL") != nullptr;       // A/B: the round-1 kernel (one thread per output voxel, corners from L2)
+    static const bool per_voxel = sn_ab_switch("SN_UPSAMPLE_PER_VOXEL") != nullptr;       // A/B: the round-1 kernel (one thread per output voxel, corners from L2)
     if (Do % 8 == 0 && Do <= 64 && !per_voxel)
         hipLaunchKernelGGL((upsample3_cat_tiled_kernel<SPLIT, OSPLIT>), dim3((unsigned)(B * 6 * (Do / 8) * (Do / 8))), dim3(256), 0, c->stream, s2.p, s3.p, s4.p,
                            cat.p, Do, cat_cs, s2.lo, s3.lo, s4.lo, cat.lo, c->mx_cat_e8);
@@ -399,7 +399,7 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     // f16x3 default (tail_m8 == 2): merge_conv_a AND merge_conv_b compute in f16m8 (main term f16, both correction terms on one MX-fp8
     // MFMA), so everything that writes the concat buffer stores it in the f16m8 format (OSPLIT = 2); upstream stays three-fp16-MFMA.
     const bool cat_m8 = SP == 1 && c->tail_m8 >= 2;
-    static const bool unfused = getenv("SN_NO_EPI_FUSION") != nullptr;      // A/B measurements: the three separate launches
+    static const bool unfused = sn_ab_switch("SN_NO_EPI_FUSION") != nullptr;      // A/B measurements: the three separate launches
     if (!unfused) {
         const SideFuse sf1{&L["side_op1"], cat, 64, 0, p1, 32};
         // (f16x3: 16x8x8 tiles as conv1_1 / conv1_2, SN_C13_MF = 8: half the weight staging and weight reads per MFMA)
@@ -593,8 +593,8 @@ static void reset_mx_exponents(sn_ctx *c)
 {
     c->mx_act_e8 = kMxActE8; c->mx_cat_e8 = kMxCatE8;
     if (c->mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0) {                                    // accuracy sweeps only (mx_format.h)
-        if (getenv("SN_MX_S_ACT")) c->mx_act_e8 = 127 - std::max(-8, std::min(8, atoi(getenv("SN_MX_S_ACT"))));
-        if (getenv("SN_MX_S_CAT")) c->mx_cat_e8 = 127 - std::max(-8, std::min(8, atoi(getenv("SN_MX_S_CAT"))));
+        if (sn_ab_switch("SN_MX_S_ACT")) c->mx_act_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_ACT"))));
+        if (sn_ab_switch("SN_MX_S_CAT")) c->mx_cat_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_CAT"))));
     }
 }
 
@@ -607,7 +607,7 @@ int sn_set_precision(sn_ctx *c, int mode)
     c->mode = mode;
     c->split = mode == SN_PRECISION_F16X3_PURE ? 1 : mode;
     c->tail_m8 = mode == SN_PRECISION_F16X3 ? 2 : 0;
-    if (mode == SN_PRECISION_F16X3 && getenv("SN_M8_TAIL")) c->tail_m8 = std::max(0, std::min(2, atoi(getenv("SN_M8_TAIL"))));   // A/B measurements only
+    if (mode == SN_PRECISION_F16X3 && sn_ab_switch("SN_M8_TAIL")) c->tail_m8 = std::max(0, std::min(2, atoi(sn_ab_switch("SN_M8_TAIL"))));   // A/B measurements only
     reset_mx_exponents(c);
     return SN_OK;
 }
@@ -805,7 +805,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
                 const float m = std::max(std::fabs(gamma[o]), std::fabs(beta[o]));
                 if (m > 0.f && std::isfinite(m)) oe[o] = std::max(-60, std::min(60, -std::ilogb(m)));
             }
-        static const bool no_bridge = getenv("SN_NO_BRIDGE") != nullptr;               // (A/B switch)
+        static const bool no_bridge = sn_ab_switch("SN_NO_BRIDGE") != nullptr;               // (A/B switch)
         L.bridge = (((SN_PPX && lsplit == 1) || ((SN_PP || SN_PW) && lsplit == 2)) && k == 3 && !no_bridge) ? 1 : 0;   // 27 K-chunks per four slabs instead of 28 (f16x3), 27 weight pieces per eight slabs instead of 32 (f16m8): pack_conv_host decides
         if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit, in_exp, oe.data())) != SN_OK) return rc;
         c->conv[L.name] = L;

@@ -70,6 +70,19 @@ struct PackedConv {
 struct ProfRec { int tag; hipEvent_t e0, e1; double flops, bytes; };
 struct ProfStat { std::string name; double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
 
+// A/B switches of the kernels' schedule and packing (SN_NO_BRIDGE, SN_NO_EPI_FUSION, SN_M8_TAIL, SN_MX_S_*, ...): read from the environment by
+// the TEST-ONLY twin library alone (Makefile target dbg, -DSN_DEBUG_HOOKS; tests/ and tools/ load it through SURFACENET_HIP_LIB). In the
+// product library they do not exist: a stray variable cannot change the K order or the code format behind the caller's back.
+static inline const char *sn_ab_switch(const char *name)
+{
+#ifdef SN_DEBUG_HOOKS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 struct sn_ctx {
     int device = 0, s = 32, max_samples = 0;
     hipStream_t stream = nullptr;
@@ -299,7 +312,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     dim3 grid((unsigned)std::min(a.total_tiles, resident), (unsigned)L.nsplit);
     {
         // phase-staggered start (only worthwhile when every workgroup walks many tiles): a quarter of the estimated tile time
-        static const int stag = getenv("SN_STAGGER") ? atoi(getenv("SN_STAGGER")) : 0;
+        static const int stag = sn_ab_switch("SN_STAGGER") ? atoi(sn_ab_switch("SN_STAGGER")) : 0;
         const int tiles_per_wg = a.total_tiles / (int)grid.x;
         if (stag && EPI == EPI_STORE && tiles_per_wg >= 8) {
             double chunks = 0;

@@ -42,7 +42,7 @@ static int simil_pack(sn_ctx *c)
         dev_free_owned(c, L.wpack); dev_free_owned(c, L.scale); dev_free_owned(c, L.shift);
         L = PackedConv();
         L.name = kSimName[i]; L.cin = kSimC[i]; L.cout = kSimC[i + 1]; L.ks = 3; L.dil = 1; L.act = 0; L.k2d = 1;
-        static const bool no_bridge = getenv("SN_SIMIL_NO_BRIDGE") != nullptr;      // (A/B switch)
+        static const bool no_bridge = sn_ab_switch("SN_SIMIL_NO_BRIDGE") != nullptr;      // (A/B switch)
         L.bridge = (want == 1 && !no_bridge) ? 1 : 0;       // f16x3: two-group slabs = 4.5 K-chunks -> 9 chunks per slab pair (pack_conv_host decides per layer)
         const float *W = c->simil_host.data() + c->simil_descs[2 * i].offset, *b = c->simil_host.data() + c->simil_descs[2 * i + 1].offset;
         std::vector<float> one((size_t)L.cout, 1.f), zero((size_t)L.cout, 0.f);

@@ -151,3 +151,16 @@ def test_packed_weight_stream_length_with_bridge_chunks(built, cin, cout, ks, k2
     halfs, bridged, total = _packed_halfs(cin, ks, taps, cs8, split, nf, nsplit)
     assert total == chunks and bridged == (ks == 3 and split != 0 and cin > 8), (total, chunks, bridged)
     assert out[0] == halfs, (out[0], halfs, bridged)
+
+
+def test_ab_switches_exist_in_the_test_twin_only():
+    """The schedule / packing A/B switches (SN_NO_BRIDGE, SN_NO_EPI_FUSION, SN_M8_TAIL, SN_MX_S_ACT ...) are compiled into the test-only twin
+    library alone: the product library does not even contain their names, so no environment variable can change its K order or code format
+    (ADVICE r3)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prod = open(os.path.join(root, "surfacenet_amd", "libsurfacenet_hip.so"), "rb").read()
+    dbg = open(os.path.join(root, "surfacenet_amd", "libsurfacenet_hip_dbg.so"), "rb").read()
+    for name in (b"SN_NO_BRIDGE", b"SN_SIMIL_NO_BRIDGE", b"SN_NO_EPI_FUSION", b"SN_UPSAMPLE_PER_VOXEL", b"SN_M8_TAIL", b"SN_MX_S_ACT", b"SN_MX_S_CAT", b"SN_STAGGER"):
+        assert name in dbg, name
+        assert name not in prod, name

@@ -394,7 +394,7 @@ def test_epilogue_fusion_equals_separate_launches(gpu_required, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for flag in ("", "1"):
-        env = dict(os.environ)
+        env = dict(os.environ, SURFACENET_HIP_LIB=os.path.join(root, "surfacenet_amd", "libsurfacenet_hip_dbg.so"))      # the A/B switches exist in the test-only twin alone
         env.pop("SN_NO_EPI_FUSION", None)
         if flag:
             env["SN_NO_EPI_FUSION"] = flag
@@ -420,7 +420,7 @@ def test_bridged_and_padded_k_order_agree(gpu_required, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for flag in ("", "1"):
-        env = dict(os.environ)
+        env = dict(os.environ, SURFACENET_HIP_LIB=os.path.join(root, "surfacenet_amd", "libsurfacenet_hip_dbg.so"))      # the A/B switches exist in the test-only twin alone
         env.pop("SN_NO_BRIDGE", None)
         if flag:
             env["SN_NO_BRIDGE"] = flag
