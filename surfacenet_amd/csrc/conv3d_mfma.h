@@ -739,6 +739,16 @@ conv3d_f16_mfma(ConvArgs a)
         // offsets of its second chunk and of its MX step. A tile's first piece loads them cold, right here.
         half8 pw_xf[PWM ? MF : 1], pw_wf[PWM ? NF : 1];
         const unsigned pw_wv = (unsigned)(wave * 1024 + lane * 16);      // this lane's bytes within this wave's first KiB of a weight piece (weight DMAs)
+        // PWM: per-slab scalars carried from slab to slab instead of re-derived (the slab boundary is the one place of the loop with no MFMA in flight:
+        // ~120 scalar instructions there were 480 clocks per slab, 3 % of the kernel): the slab's first unit (bridge pieces), and the base of the
+        // halo tile staged during the slab (one 8-channel group plane further per slab; behind the tile's last slab the next tile's first group)
+        int pw_o = 0;
+        const char *pw_hnext = nullptr, *pw_hptr = nullptr;
+        if constexpr (PWM) {
+            const bool hn = tile + tstride < a.total_tiles;
+            pw_hptr = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)b * VOL * a.in_cs) + VOL * 16;                 // slab 0 stages slab 1
+            pw_hnext = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)(hn ? nxt_b : b) * VOL * a.in_cs);             // (no next tile: this tile's first slab once more, the buffer is idle)
+        }
         int pw_koB = 0;
         long long pw_k2 = 0;
         if constexpr (PWM) {
@@ -754,17 +764,22 @@ conv3d_f16_mfma(ConvArgs a)
             lgkm_wait<0>();
         }
         for (int slab = 0; slab < a.nslab; ++slab) {
-            const int c8n = slab_c8_of(slab);
-            const int nchunk = chunks_of(c8n, slab);
+            const bool last_slab = slab + 1 == a.nslab;
+            const int c8n = PWM ? 1 : slab_c8_of(slab);          // (PWM: one 8-channel group per slab, launch_conv checks)
+            int nchunk, wchunk;
+            if constexpr (PWM) {
+                // units of this slab's pieces: 27 - o of its own (o: taken by the slab before) + b of the next slab's (slab_units, branch-free on the carried o)
+                const int bmask = (bridge && !last_slab) ? 7 : 0;
+                const int units = C::NTAP - pw_o + ((8 - ((C::NTAP - pw_o) & 7)) & bmask);
+                nchunk = (units + 3) >> 2; wchunk = ((units + 7) >> 3) << 1;
+            } else { nchunk = chunks_of(c8n, slab); wchunk = wchunks_of(c8n, slab); }
             const int npiece = (nchunk + C::PCH - 1) / C::PCH;
             // what comes after this slab: next slab of this tile, or slab 0 of this workgroup's next tile
-            const bool last_slab = slab + 1 == a.nslab;
             const int ntile = last_slab ? tile + tstride : tile;
             const bool have_next = ntile < a.total_tiles;
             const int nslab_i = last_slab ? 0 : slab + 1;
-            const int nc8n = slab_c8_of(nslab_i);
+            const int nc8n = PWM ? 1 : slab_c8_of(nslab_i);
             const int nc0 = last_slab ? 0 : c0 + c8n;
-            const int wchunk = wchunks_of(c8n, slab);
             const size_t nwoff = last_slab ? 0 : woff + (size_t)wchunk * NF * C::FRAG;
             if constexpr (!PP && !PWM) { if (have_next) write_koff(nc8n, xb ^ 1, nslab_i); }
             // the next halo tile is fetched in npiece-1 instalments, each issued right after a weight piece so that a
@@ -797,19 +812,18 @@ conv3d_f16_mfma(ConvArgs a)
                 const unsigned ntab_a = kbuf_a + (unsigned)(((xb ^ 1) * C::PW_SLABS + nslab_i) * (C::KOFF_N * 4));
                 const unsigned xs_a = xbuf_a + xb * C::XBUF + (unsigned)xbase[0];
                 const unsigned nxs_a = xbuf_a + (xb ^ 1) * C::XBUF + (unsigned)xbase[0];
-                // the halo tile staged during this slab's first piece: the next slab's / the next tile's first slab; behind the launch's last
-                // slab this tile's first slab once more (branch-free issue, the buffer is idle)
-                int hb = have_next ? (last_slab ? nxt_b : b) : b, htoff = have_next ? (last_slab ? nxt_toff : cur_toff) : cur_toff;
-                unsigned hkeep = have_next ? (last_slab ? nxt_keep : cur_keep) : cur_keep;
-                int hc0 = have_next ? nc0 : 0, hc8n = have_next ? nc8n : slab_c8_of(0);
-                hb = __builtin_amdgcn_readfirstlane(hb); htoff = __builtin_amdgcn_readfirstlane(htoff); hkeep = __builtin_amdgcn_readfirstlane(hkeep);
-                hc0 = __builtin_amdgcn_readfirstlane(hc0); hc8n = __builtin_amdgcn_readfirstlane(hc8n);
+                // the halo tile staged during this slab's first two pieces: the next slab's / the next tile's first slab (carried pointers, see the tile loop)
+                const bool hnext = last_slab && have_next;
+                int htoff = hnext ? nxt_toff : cur_toff;
+                unsigned hkeep = hnext ? nxt_keep : cur_keep;
+                htoff = __builtin_amdgcn_readfirstlane(htoff); hkeep = __builtin_amdgcn_readfirstlane(hkeep);
+                const char *const hbase = last_slab ? pw_hnext : pw_hptr;
                 auto halo_rsrc = [&](int plane) {
-                    const char *base = reinterpret_cast<const char *>(a.in) + 2 * ((size_t)hb * VOL * a.in_cs + (size_t)hc0 * VOL * 8) + (plane ? 2 * a.in_lo_off : 0);
+                    const char *base = hbase + (plane ? 2 * a.in_lo_off : 0);
                     const unsigned long long bq = (unsigned long long)(size_t)base;
                     base = (const char *)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bq >> 32)) << 32) |
                                                   (unsigned)__builtin_amdgcn_readfirstlane((int)bq));
-                    return __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, __builtin_amdgcn_readfirstlane(hc8n * (int)VOL * 16), 0x00020000);
+                    return __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, __builtin_amdgcn_readfirstlane((int)VOL * 16), 0x00020000);
                 };
                 // halo descriptors of the slab staged during this one: the f16 plane goes out with the slab's first piece, the code plane with its second
                 static_assert(HT % 2 == 0 && C::NSEG * NPL == HT * C::NW && (HT / 2) * C::NW == C::NSEG && WCNT % C::NW == 0, "PWM DMA schedule");
@@ -1663,6 +1677,7 @@ conv3d_f16_mfma(ConvArgs a)
             xb ^= 1;
             c0 += c8n;
             woff += (size_t)wchunk * NF * C::FRAG;
+            if constexpr (PWM) { pw_o = bridge ? (pw_o + 5) & 7 : 0; pw_hptr += VOL * 16; }      // (27 units per slab, pieces of 8: the next slab starts 5 units later mod 8)
         }
 
         if constexpr (PP && SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }     // pairs with group 1's last compute segment of the tile
