@@ -126,7 +126,8 @@ def s64_mode(surfacenet_amd, values, n_vp, device, steps, precision, n=32):
             "workload": "one GPU's shard of BASELINE.json configs[3]: s=64, 256 cubes over 8 GPUs = %d cubes x %d view pairs per step" % (n, n_vp),
             "equivalent_s32_cubes_per_s": round(8 * n * steps / el, 1),
             "roofline": {"bound": "mfma", "kernel": "conv3d_f16_mfma<%s>" % dom, "achieved": round(ach, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4)}}
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "avg_launch_ms": round(prof[dom]["ms"] / prof[dom]["launches"], 4),
+                         "launches": prof[dom]["launches"]}}
 
 
 def post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, steps, keep_frac=0.1):

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--cube-d", type=int, default=32)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--precision", default="f16x3")
-    ap.add_argument("--layers", nargs="*", default=["merge_conv_b=3,1,4,7,1,2,1,2,8,0,0,-1", "merge_conv_a=3,1,4,7,0,2,1,2,8,0,0,-1"],
+    ap.add_argument("--layers", nargs="*", default=["merge_conv_b=3,1,8,7,1,2,1,2,4,0,0,-1", "merge_conv_a=3,1,8,7,0,2,1,2,4,0,0,-1"],      # (round 4: the 4-wave PWM instantiations)
                     help="layer=template-argument list of its conv3d_f16_mfma instantiation")
     a = ap.parse_args()
     import bench
