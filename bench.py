@@ -22,6 +22,8 @@ import time
 
 import numpy as np
 
+NATIVE_COMM_DEADLINE_S = 180      # --gpus N: the library's own RCCL communicator must be up (and verified) within this, else torch.distributed carries the exchange
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -281,29 +283,47 @@ def main():
     ctx.set_images(scene["imgs"])
     d_pairs, d_xyz, d_resol, d_w = (ctx.upload(scene[k]) for k in ("pairs", "xyz", "resol", "w"))
     native = use_dist and not (args.torch_comm or bool(os.environ.get("BENCH_TORCH_COMM")))
-    comm_note = None
+    comm_note, native_hung = None, False
     if native:
         # the C ABI's own exchange: rank 0 draws the RCCL unique id, torch.distributed ships its 128 bytes, every rank joins; then one small
         # all-gather through the library is compared with torch.distributed's. Any failure on any rank -> every rank falls back to torch.
-        ok, why = 1, ""
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
+        # The set-up runs in a helper thread with a deadline: a communicator that never forms (the binding has only ever met a one-rank group on
+        # the builder's boxes) must cost a note in the JSON line, not the scaling run.
+        import threading
+        state = {"ok": 0, "why": "native communicator set-up did not finish within %d s" % NATIVE_COMM_DEADLINE_S}
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            try:
                 uid.copy_(torch.frombuffer(bytearray(surfacenet_amd.Context.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, src=0)
-            ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
-            probe = (np.arange(4096, dtype=np.float32) + 10000.0 * rank)
-            d_p, d_pg = ctx.upload(probe), ctx.dev_alloc(world * probe.nbytes)
-            ctx.allgather_f32_dev_overlap(d_p, probe.size, d_pg, 7)
-            ctx.synchronize()
-            got = np.empty((world * probe.size,), np.float32)
-            ctx.d2h(got, d_pg)
-            want = np.concatenate([np.arange(4096, dtype=np.float32) + 10000.0 * r for r in range(world)])
-            if not np.array_equal(got, want):
-                ok, why = 0, "native all-gather returned wrong data"
-            ctx.dev_free(d_p); ctx.dev_free(d_pg)
-        except Exception as e:      # noqa: BLE001 - whatever went wrong, the scaling run must still produce a number
-            ok, why = 0, "%s: %s" % (type(e).__name__, e)
+            except Exception as e:      # noqa: BLE001
+                state["why"] = "%s: %s" % (type(e).__name__, e)
+        dist.broadcast(uid, src=0)
+        uid_bytes = bytes(uid.cpu().numpy().tobytes())
+
+        def _native_setup():
+            try:
+                torch.cuda.set_device(local_rank)
+                ctx.comm_init(world, rank, uid_bytes)
+                probe = (np.arange(4096, dtype=np.float32) + 10000.0 * rank)
+                d_p, d_pg = ctx.upload(probe), ctx.dev_alloc(world * probe.nbytes)
+                ctx.allgather_f32_dev_overlap(d_p, probe.size, d_pg, 7)
+                ctx.synchronize()
+                got = np.empty((world * probe.size,), np.float32)
+                ctx.d2h(got, d_pg)
+                want = np.concatenate([np.arange(4096, dtype=np.float32) + 10000.0 * r for r in range(world)])
+                ctx.dev_free(d_p); ctx.dev_free(d_pg)
+                if np.array_equal(got, want):
+                    state["ok"] = 1
+                else:
+                    state["why"] = "native all-gather returned wrong data"
+            except Exception as e:      # noqa: BLE001 - whatever went wrong, the scaling run must still produce a number
+                state["why"] = "%s: %s" % (type(e).__name__, e)
+
+        th = threading.Thread(target=_native_setup, daemon=True)
+        th.start()
+        th.join(NATIVE_COMM_DEADLINE_S)
+        native_hung = th.is_alive()
+        ok, why = (0 if native_hung else state["ok"]), state["why"]
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
@@ -451,6 +471,9 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if native_hung:             # a helper thread is still stuck inside the RCCL set-up: do not wait for it at interpreter exit
+        sys.stdout.flush()
+        os._exit(0)
     if ctx is not None:
         ctx.close()
 
