@@ -372,7 +372,10 @@ struct ConvCfg {
     // LDS distance of voxel fragment m from fragment 0 of the same lane under the row-gap-4 map (frag_xyz: hx = wave * XS + (m >> 2), hy = (m & 3) + 4 (v >> 3)):
     // a compile-time constant, so the PWM loop addresses all fragments as one per-lane register + the read's immediate offset
     static constexpr int pw_xoff(int m) { return (((m >> 2) * HY + (m & 3)) * HZ) * VS; }
-    static constexpr int KTAB_N = PWM ? PW_SLABS * KOFF_N : KOFF_N;   // ints per halo buffer
+    // f16x3 3x3(x3) kernels on the ping-pong loop (PTAB): a slab's tap table depends only on the halo buffer it sits in, on its first unit (a function of
+    // slab mod 4 with bridge chunks: 27 or 18 units per slab, 4 per chunk) and on whether it is the tile's last (b = 0, possibly fewer groups) - 8 tables per buffer, written once per launch instead of once per slab in a load slot
+    static constexpr bool PTAB = SN_PPX && SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && (K2D == 0 || SPLIT != 0) && !PWM;      // (= the kernels of the f16 / f16x3 ping-pong loop, 3-D and 2-D)
+    static constexpr int KTAB_N = PWM ? PW_SLABS * KOFF_N : (PTAB ? 8 * KOFF_N : KOFF_N);   // ints per halo buffer
     static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
     static constexpr int XPLANE = NSEG * 1024;
     static constexpr int XBUF = XPLANE * NPL;
@@ -608,13 +611,13 @@ conv3d_f16_mfma(ConvArgs a)
     auto write_koff_part = [&](int c8n, int kb, int slab, int t0, int nt) {
         int uo, ub;
         const int own = slab_units(c8n, slab, uo, ub) - ub, nchunk = (own + ub + 3) >> 2;
-        int *k = kbuf + (PWM ? kb * C::PW_SLABS + slab : kb) * C::KOFF_N;
+        int *k = kbuf + (PWM ? kb * C::PW_SLABS + slab : (C::PTAB ? kb * 8 + ((slab + 1 == a.nslab) ? 4 : 0) + (slab & 3) : kb)) * C::KOFF_N;
         for (int g = t0; g < (nchunk + 4) * 4; g += nt) {
             int o = 0;
             if (g < own + ub) {
                 const int u = g < own ? g + uo : g - own;                       // unit of this slab | bridge: of the next one, in the other halo buffer
                 const int far = g < own ? 0 : (1 - 2 * kb) * C::XBUF;
-                const int tap = u / c8n, c8 = u - tap * c8n;
+                const int tap = C::CS8MAX == 1 ? u : u / c8n, c8 = C::CS8MAX == 1 ? 0 : u - tap * c8n;      // (one-group slabs: no run-time division in the load slot that carries the table write)
                 const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
                 o = ((dx * DIL * C::HY + dy * DIL) * C::HZ + dz * DIL) * C::VS + c8 * 16 + far;
             }
@@ -680,6 +683,11 @@ conv3d_f16_mfma(ConvArgs a)
             tile_halo_consts(x0, y0, z0, keep, toff);
             stage_halo_buf(K2D ? x0 : b, keep, toff, 0, c8n, 0);
         } else stage_halo(tile, 0, c8n, 0, 0, HT);
+        if constexpr (C::PTAB) {      // the 8 tables per halo buffer (see ConvCfg::PTAB): slabs 0..3 as representatives of their residue, the last slab once per residue
+            for (int kb = 0; kb < 2; ++kb)
+                for (int sl = 0; sl < a.nslab; ++sl)
+                    if (sl < 4 || sl + 1 == a.nslab) write_koff(slab_c8_of(sl), kb, sl);
+        } else
         if constexpr (PWM) {      // every slab's tap table, for either halo buffer it may land in (the bridge entries depend on the buffer)
             for (int kb = 0; kb < 2; ++kb)
                 for (int sl = 0; sl < a.nslab; ++sl) write_koff(slab_c8_of(sl), kb, sl);
@@ -990,7 +998,7 @@ conv3d_f16_mfma(ConvArgs a)
                 // SEGC = 2 where a chunk is a short burst (conv1_x: 24 MFMAs): halves the barriers per MFMA
                 constexpr int SEGC = (SN_PPX_SEGC == 2 && MF * NF <= 8 && C::PCH >= 3) ? 2 : 1;
                 constexpr int NSEGMAX = (C::PCH + SEGC - 1) / SEGC;
-                const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
+                const unsigned koff_a = kbuf_a + (unsigned)((C::PTAB ? xb * 8 + (last_slab ? 4 : 0) + (slab & 3) : xb) * (C::KOFF_N * 4));
                 const unsigned xslab = xbuf_a + xb * C::XBUF;
                 constexpr int NPLM = C::NPLM;
                 int ko[SEGC], ko_n[SEGC];
@@ -1057,7 +1065,7 @@ conv3d_f16_mfma(ConvArgs a)
                                     const int cnt = w_nch * NF * NPL;
                                     for (int i = wave; i < cnt; i += C::NW) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
                                 }
-                                if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, nslab_i, tid, C::NT / 2);
+                                if constexpr (!C::PTAB) { if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, nslab_i, tid, C::NT / 2); }
                             }
                             // the next slab's halo tile: second segment of the slab's first piece (first segment if the piece has only one)
                             if (p == 0 && have_next && !(SN_ABL & 1) && sc == (nseg >= 2 ? 1 : 0))
