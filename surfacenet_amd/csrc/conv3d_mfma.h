@@ -592,6 +592,7 @@ conv3d_f16_mfma(ConvArgs a)
     // 13 are 44 instead of 52; the bridge piece is a slab's third or fourth, behind the vmcnt(0) of the second piece's MX load slot.
     constexpr bool BRIDGE_OK = (PPX && SPLIT == 1 && SN_PPX_SEGC == 1) || PPM || PWM;
     constexpr int UM = SPLIT == 2 ? 8 : 4;                   // units per chunk / per piece: what a slab's unit count is rounded up to
+    constexpr int BSTEP = (UM - (C::NTAP * C::CS8MAX) % UM) % UM;      // bridged layers (all slabs hold CS8MAX groups): a slab starts this many units later (mod UM) than its predecessor
     const bool bridge = BRIDGE_OK && a.bridge != 0;
     // units of slab `slab` in its chunks: GU - o of its own (o: taken by the slab before) + b of the next slab's
     auto slab_units = [&](int c8n, int slab, int &o, int &b) {
@@ -606,6 +607,7 @@ conv3d_f16_mfma(ConvArgs a)
     auto chunks_of = [&](int c8n, int slab) { int o, b; return (slab_units(c8n, slab, o, b) + 3) >> 2; };
     // K-chunks the weight STREAM holds for a slab (f16m8 pads every slab to whole pieces)
     auto wchunks_of = [&](int c8n, int slab) { int o, b; return SPLIT == 2 ? (((slab_units(c8n, slab, o, b) + 7) >> 3) << 1) : chunks_of(c8n, slab); };
+    const int wchunk0 = wchunks_of(slab_c8_of(0), 0);        // ... of a tile's first slab
     // tap table of slab `slab` (c8n groups) into table buffer kb (= the halo buffer that holds the slab): entry g = LDS byte offset of
     // (tap, group) unit g's 16-byte slot relative to a voxel's own slot
     auto write_koff_part = [&](int c8n, int kb, int slab, int t0, int nt) {
@@ -747,10 +749,11 @@ conv3d_f16_mfma(ConvArgs a)
         // offsets of its second chunk and of its MX step. A tile's first piece loads them cold, right here.
         half8 pw_xf[PWM ? MF : 1], pw_wf[PWM ? NF : 1];
         const unsigned pw_wv = (unsigned)(wave * 1024 + lane * 16);      // this lane's bytes within this wave's first KiB of a weight piece (weight DMAs)
-        // PWM: per-slab scalars carried from slab to slab instead of re-derived (the slab boundary is the one place of the loop with no MFMA in flight:
-        // ~120 scalar instructions there were 480 clocks per slab, 3 % of the kernel): the slab's first unit (bridge pieces), and the base of the
-        // halo tile staged during the slab (one 8-channel group plane further per slab; behind the tile's last slab the next tile's first group)
-        int pw_o = 0;
+        // Per-slab scalars carried from slab to slab instead of re-derived (slab_units with its branches, three to four times per slab): the slab's first unit
+        // (all loops), and - PWM, where the slab boundary is the one place with no MFMA in flight: ~120 scalar instructions there were 480 clocks per slab,
+        // 3 % of the kernel - the base of the halo tile staged during the slab (one 8-channel group plane further per slab; behind the tile's last slab the
+        // next tile's first group)
+        int sl_o = 0;             // first (tap, group) unit of the current slab's chunk / piece sequence (bridge chunks: the units before it went to the slab before)
         const char *pw_hnext = nullptr, *pw_hptr = nullptr;
         if constexpr (PWM) {
             const bool hn = tile + tstride < a.total_tiles;
@@ -773,20 +776,22 @@ conv3d_f16_mfma(ConvArgs a)
         }
         for (int slab = 0; slab < a.nslab; ++slab) {
             const bool last_slab = slab + 1 == a.nslab;
-            const int c8n = PWM ? 1 : slab_c8_of(slab);          // (PWM: one 8-channel group per slab, launch_conv checks)
-            int nchunk, wchunk;
-            if constexpr (PWM) {
-                // units of this slab's pieces: 27 - o of its own (o: taken by the slab before) + b of the next slab's (slab_units, branch-free on the carried o)
-                const int bmask = (bridge && !last_slab) ? 7 : 0;
-                const int units = C::NTAP - pw_o + ((8 - ((C::NTAP - pw_o) & 7)) & bmask);
-                nchunk = (units + 3) >> 2; wchunk = ((units + 7) >> 3) << 1;
-            } else { nchunk = chunks_of(c8n, slab); wchunk = wchunks_of(c8n, slab); }
+            const int c8n = last_slab ? a.c8_last : C::CS8MAX;
+            // units of this slab's chunks / pieces: GU - o of its own (o: taken by the slab before) + b of the next slab's (slab_units, branch-free on the carried o)
+            const int su_o = sl_o, su_b = (UM - ((C::NTAP * c8n - su_o) & (UM - 1))) & ((bridge && !last_slab) ? UM - 1 : 0);
+            const int units = C::NTAP * c8n - su_o + su_b;
+            const int nchunk = (units + 3) >> 2, wchunk = SPLIT == 2 ? ((units + 7) >> 3) << 1 : nchunk;
             const int npiece = (nchunk + C::PCH - 1) / C::PCH;
             // what comes after this slab: next slab of this tile, or slab 0 of this workgroup's next tile
             const int ntile = last_slab ? tile + tstride : tile;
             const bool have_next = ntile < a.total_tiles;
             const int nslab_i = last_slab ? 0 : slab + 1;
-            const int nc8n = PWM ? 1 : slab_c8_of(nslab_i);
+            const bool nlast = nslab_i + 1 == a.nslab;
+            const int nc8n = nlast ? a.c8_last : C::CS8MAX;
+            // ... and the K-chunks its weight stream holds (the size of its first weight piece)
+            const int n_o = (bridge && !last_slab) ? (su_o + BSTEP) & (UM - 1) : 0;
+            const int n_units = C::NTAP * nc8n - n_o + ((UM - ((C::NTAP * nc8n - n_o) & (UM - 1))) & ((bridge && !nlast) ? UM - 1 : 0));
+            const int n_wchunk = SPLIT == 2 ? ((n_units + 7) >> 3) << 1 : (n_units + 3) >> 2;
             const int nc0 = last_slab ? 0 : c0 + c8n;
             const size_t nwoff = last_slab ? 0 : woff + (size_t)wchunk * NF * C::FRAG;
             if constexpr (!PP && !PWM) { if (have_next) write_koff(nc8n, xb ^ 1, nslab_i); }
@@ -1003,7 +1008,7 @@ conv3d_f16_mfma(ConvArgs a)
                 constexpr int NPLM = C::NPLM;
                 int ko[SEGC], ko_n[SEGC];
                 int bridge_o = 0, bridge_b = 0;                     // bridge chunks (write_koff_part): units this slab's last chunk takes from the next slab
-                if (bridge) slab_units(c8n, slab, bridge_o, bridge_b);
+                bridge_o = su_o; bridge_b = su_b;
                 static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_read32<j * 16>(ko[j], koff_a); ko_n[j] = 0; });
                 lgkm_wait<0>();
                 int p = 0;
@@ -1017,7 +1022,7 @@ conv3d_f16_mfma(ConvArgs a)
                     const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
                     int w_nch = C::PCH;
                     if (p + 1 < npiece) { const int rem = wchunk - (ch0 + C::PCH); if (rem < C::PCH) w_nch = rem; }
-                    else { const int nch = wchunks_of(nc8n, nslab_i); if (nch < C::PCH) w_nch = nch; }
+                    else { if (n_wchunk < C::PCH) w_nch = n_wchunk; }
                     int hnow = 0;
                     static_for<0, NSEGMAX>([&](auto scc) {
                         constexpr int sc = decltype(scc)::value;
@@ -1050,7 +1055,7 @@ conv3d_f16_mfma(ConvArgs a)
                                     const bool real = w_next;
                                     const char *src = wsrc0 + (real ? w_off : 0);
                                     char *dst = wbuf + (wbi ^ 1) * C::WBUF;
-                                    const int nch0 = wchunks_of(slab_c8_of(0), 0);
+                                    const int nch0 = wchunk0;
                                     const int cnt = (real ? w_nch : (nch0 < C::PCH ? nch0 : C::PCH)) * NF * NPL;
                                     constexpr int WPWX = (C::PCH * NF * NPL + C::NW - 1) / C::NW;
                                     static_for<0, WPWX>([&](auto kc) {
@@ -1411,7 +1416,7 @@ conv3d_f16_mfma(ConvArgs a)
                         const int rem = wchunk - (ch0 + C::PCH);
                         stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
                     } else if (have_next) {
-                        const int nch = wchunks_of(nc8n, nslab_i);
+                        const int nch = n_wchunk;
                         stage_w(nwoff, nch < C::PCH ? nch : C::PCH, wbi ^ 1);
                     }
                     if constexpr (BUFH) {
@@ -1685,7 +1690,8 @@ conv3d_f16_mfma(ConvArgs a)
             xb ^= 1;
             c0 += c8n;
             woff += (size_t)wchunk * NF * C::FRAG;
-            if constexpr (PWM) { pw_o = bridge ? (pw_o + 5) & 7 : 0; pw_hptr += VOL * 16; }      // (27 units per slab, pieces of 8: the next slab starts 5 units later mod 8)
+            sl_o = n_o;
+            if constexpr (PWM) pw_hptr += VOL * 16;
         }
 
         if constexpr (PP && SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }     // pairs with group 1's last compute segment of the tile
