@@ -372,6 +372,9 @@ struct ConvCfg {
     // LDS distance of voxel fragment m from fragment 0 of the same lane under the row-gap-4 map (frag_xyz: hx = wave * XS + (m >> 2), hy = (m & 3) + 4 (v >> 3)):
     // a compile-time constant, so the PWM loop addresses all fragments as one per-lane register + the read's immediate offset
     static constexpr int pw_xoff(int m) { return (((m >> 2) * HY + (m & 3)) * HZ) * VS; }
+    // the same under the row-gap-2 map (hy = (m & 1) + 4 ((m >> 1) & 1) + 2 (v >> 3)); XGAP = the map this kernel's 3-D form uses (frag_xyz)
+    static constexpr int XGAP = DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3;
+    static constexpr int xoff_of(int m) { return XGAP == 4 ? pw_xoff(m) : (((m >> 2) * HY + (m & 1) + 4 * ((m >> 1) & 1)) * HZ) * VS; }
     // f16x3 3x3(x3) kernels on the ping-pong loop (PTAB): a slab's tap table depends only on the halo buffer it sits in, on its first unit (a function of
     // slab mod 4 with bridge chunks: 27 or 18 units per slab, 4 per chunk) and on whether it is the tile's last (b = 0, possibly fewer groups) - 8 tables per buffer, written once per launch instead of once per slab in a load slot
     static constexpr bool PTAB = SN_PPX && SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && (K2D == 0 || SPLIT != 0) && !PWM;      // (= the kernels of the f16 / f16x3 ping-pong loop, 3-D and 2-D)
@@ -1032,12 +1035,21 @@ conv3d_f16_mfma(ConvArgs a)
                                 constexpr int j = decltype(jc)::value, cc = sc * SEGC + j;
                                 if (SEGC == 1 || cc < nch_p) {
                                     const unsigned kos = xslab + (unsigned)ko[j];
+                                    // XIMM: under the row-gap maps of the 3-D kernels the distance of fragment m from fragment 0 is a compile-time constant
+                                    // (ConvCfg::xoff_of): one address register + immediate offsets instead of an add per read in the load slot
+                                    constexpr bool XIMM = K2D == 0 && !PMAP && KS == 3 && (C::XGAP == 4 || C::XGAP == 2) && C::XPLANE + C::xoff_of(MF - 1) < 65536;
+                                    const unsigned kos0 = (unsigned)xbase[0] + kos;
                                     static_for<0, MF>([&](auto mc) {
                                         constexpr int m = decltype(mc)::value;
+                                        if constexpr (XIMM) {
+                                            lds_read128<C::xoff_of(m)>(xf[j][0][m], kos0);
+                                            if constexpr (SPLIT == 1) lds_read128<C::XPLANE + C::xoff_of(m)>(xf[j][1][m], kos0);
+                                        } else {
                                         lds_read128<0>(xf[j][0][m], (unsigned)xbase[m] + kos);
                                         if constexpr (SPLIT == 1) {
                                             if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(xf[j][1][m], (unsigned)xbase[m] + kos);
                                             else lds_read128<0>(xf[j][1][m], (unsigned)xbase[m] + kos + C::XPLANE);
+                                        }
                                         }
                                     });
                                     static_for<0, NF>([&](auto nc) {
