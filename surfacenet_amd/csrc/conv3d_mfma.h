@@ -1985,10 +1985,15 @@ conv3d_f16_mfma(ConvArgs a)
             // The folded BN constants of all NF fragments are fetched BEFORE the first store (the K loop's operand registers are free by now): a
             // global load between stores makes hipcc wait vmcnt(0) in front of its use, i.e. for the stores issued before it - one HBM round trip
             // per (fragment pair, cout fragment): 8-10 per tile, a third of conv1_x's tile time (round 3; wide layers keep theirs in LDS, CST_LDS)
-            f32x4 scv[C::CST_LDS ? 1 : NF], shv[C::CST_LDS ? 1 : NF];
-            if constexpr (!C::CST_LDS) {
+            // (CST_LDS, round 4: likewise all 2 NF reads up front - one LDS round trip per tile instead of one exposed lgkmcnt(0) per (fragment pair, cout
+            // fragment): 28 x ~120 clocks of merge_conv_a's 17,000-clock epilogue; the K loop's operand registers are free by now)
+            f32x4 scv[NF], shv[NF];
 #pragma unroll
-                for (int n = 0; n < NF; ++n) {
+            for (int n = 0; n < NF; ++n) {
+                if constexpr (C::CST_LDS) {
+                    scv[n] = *reinterpret_cast<const f32x4 *>(cstl + n * 16);
+                    shv[n] = *reinterpret_cast<const f32x4 *>(cstl + NF * 16 + n * 16);
+                } else {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
                     const int nlc = nl < a.out_cp ? nl : 0;
                     scv[n] = *reinterpret_cast<const f32x4 *>(a.scale + nlc);
@@ -2012,8 +2017,7 @@ conv3d_f16_mfma(ConvArgs a)
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
                     const bool ch_ok = nl < a.out_cp;                    // out_cp is a multiple of 8: both lanes of a pair agree
-                    const f32x4 sc = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cstl + n * 16) : scv[C::CST_LDS ? 0 : n];
-                    const f32x4 sh = C::CST_LDS ? *reinterpret_cast<const f32x4 *>(cstl + NF * 16 + n * 16) : shv[C::CST_LDS ? 0 : n];
+                    const f32x4 sc = scv[n], sh = shv[n];
                     unsigned hw[2][2], lw[2][2];                          // [fragment of the pair][dword]: hi plane, second plane
                     _Float16 hq[2][4];
                     float loq[2][4];
@@ -2021,9 +2025,16 @@ conv3d_f16_mfma(ConvArgs a)
                     for (int e = 0; e < 2; ++e) {
                         half4 h, l;
                         float lo32[4];
+                        // BN affine on register PAIRS (v_pk_mul_f32 + v_pk_add_f32: two values per instruction; separate roundings as before)
+                        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                        const f32x4 av = acc[mp + e][n];
+                        f32x2_ pre01 = av.xy * sc.xy, pre23 = av.zw * sc.zw;
+                        asm("" : "+v"(pre01), "+v"(pre23));           // (kept as register pairs: hipcc otherwise splits the packed operations back into scalar ones)
+                        pre01 += sh.xy; pre23 += sh.zw;
+                        const float prev[4] = {pre01.x, pre01.y, pre23.x, pre23.y};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float pre = acc[mp + e][n][r] * sc[r] + sh[r];
+                            const float pre = prev[r];
                             float y = ACT == 0 ? fmaxf(pre, 0.f) : sn_sigmoid(pre);
                             if constexpr (OSPLIT == 1) {
                                 _Float16 hh, ll;
