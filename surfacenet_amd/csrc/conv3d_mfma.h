@@ -777,6 +777,9 @@ conv3d_f16_mfma(ConvArgs a)
             static_for<0, NF>([&](auto nc) { constexpr int n = decltype(nc)::value; lds_read128<n * 1024>(pw_wf[n], wp0); });
             lgkm_wait<0>();
         }
+        // (launch_conv: nslab >= 1. Said out loud because the zero-trip path around the slab loop, never taken, otherwise meets the loop's exit in front of the
+        // epilogue with the accumulators in a different register assignment: ~220 AGPR-to-AGPR copies per tile on the path that is taken)
+        if constexpr (PWM) __builtin_assume(a.nslab >= 1);       // (the eight-wave kernels: conv4_x / conv1_3 +1 % with it - left as they were)
         for (int slab = 0; slab < a.nslab; ++slab) {
             const bool last_slab = slab + 1 == a.nslab;
             const int c8n = last_slab ? a.c8_last : C::CS8MAX;
@@ -2105,9 +2108,17 @@ conv3d_f16_mfma(ConvArgs a)
                 const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + nl);
                 const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.w3 + nl);
 #pragma unroll
-                for (int m = 0; m < MF; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pm[m] += fmaxf(acc[m][n][r] * sc[r] + sh[r], 0.f) * w3[r];
+                for (int m = 0; m < MF; ++m) {
+                    // (register pairs: packed multiply / add / multiply, separate roundings and the same summation order as the scalar form)
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x4 av = acc[m][n];
+                    f32x2_ t01 = av.xy * sc.xy, t23 = av.zw * sc.zw;
+                    asm("" : "+v"(t01), "+v"(t23));
+                    t01 += sh.xy; t23 += sh.zw;
+                    f32x2_ q01 = f32x2_{fmaxf(t01.x, 0.f), fmaxf(t01.y, 0.f)} * w3.xy, q23 = f32x2_{fmaxf(t23.x, 0.f), fmaxf(t23.y, 0.f)} * w3.zw;
+                    asm("" : "+v"(q01), "+v"(q23));
+                    pm[m] += q01.x; pm[m] += q01.y; pm[m] += q23.x; pm[m] += q23.y;
+                }
             }
 #pragma unroll
             for (int m = 0; m < MF; ++m) {

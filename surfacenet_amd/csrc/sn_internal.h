@@ -293,6 +293,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
         a.status_bit = bit < 31 ? (1u << bit) : (1u << 31);
     }
     a.nslab = (int)L.slab_c8.size();
+    if (a.nslab < 1) return fail(SN_ERR_STATE, "%s: no channel slabs", L.name.c_str());      // (the kernel assumes at least one)
     a.bridge = L.bridge;
     if (L.bridge && !sn::sn_conv_has_bridge<KS, SPLIT, NW, PCH, NF, K2D, MF>())
         return fail(SN_ERR_STATE, "%s: packed with bridge chunks, launched on a kernel without them", L.name.c_str());
