@@ -1023,16 +1023,14 @@ conv3d_f16_mfma(ConvArgs a)
                     const unsigned wp = wbuf_a + wbi * C::WBUF;
                     const int nch_p = (nchunk - ch0) < C::PCH ? (nchunk - ch0) : C::PCH;      // chunks of this piece (>= 1)
                     const int nseg = (nch_p + SEGC - 1) / SEGC;                             // ... in segments
-                    // the piece after this one: next piece of the slab (possibly short), else the first piece of the next slab / tile
-                    const bool w_next = (p + 1 < npiece) || have_next;
-                    const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
-                    int w_nch = C::PCH;
-                    if (p + 1 < npiece) { const int rem = wchunk - (ch0 + C::PCH); if (rem < C::PCH) w_nch = rem; }
-                    else { if (n_wchunk < C::PCH) w_nch = n_wchunk; }
                     int hnow = 0;
                     static_for<0, NSEGMAX>([&](auto scc) {
                         constexpr int sc = decltype(scc)::value;
                         if (sc < nseg) {
+                            // SN_TIMING 1 / 2 (diagnostic builds; this loop): per segment {load slot up to the barrier, wait at that barrier} / {MFMA burst, wait at the closing barrier}
+                            long long pxt[5] = {0, 0, 0, 0, 0};
+#define PX_T(i) do { if constexpr (SN_TIMING == 1 || SN_TIMING == 2 || SN_TIMING == 5) { pxt[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
+                            PX_T(0);
                             half8 xf[SEGC][NPLM][MF], wf[SEGC][NPLM][NF];
                             static_for<0, SEGC>([&](auto jc) {
                                 constexpr int j = decltype(jc)::value, cc = sc * SEGC + j;
@@ -1063,7 +1061,15 @@ conv3d_f16_mfma(ConvArgs a)
                                 }
                                 lds_read32<0>(ko_n[j], koff_a + (unsigned)(ch0 + (sc + 1) * SEGC + j) * 16);      // tap offsets of the next segment's chunks
                             });
+                            // (tried, A/B r4aa: a scheduling barrier here, so that the DMA duties and their ~35 scalar instructions go out behind the operand reads - no
+                            // change anywhere: the load slot is bounded by the LDS itself, 4 loading waves x 16 KiB per 768-clock burst of the partner group)
                             if constexpr (sc == 0) {
+                                // the piece after this one: next piece of the slab (possibly short), else the first piece of the next slab / tile
+                                const bool w_next = (p + 1 < npiece) || have_next;
+                                const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
+                                int w_nch = C::PCH;
+                                if (p + 1 < npiece) { const int rem = wchunk - (ch0 + C::PCH); if (rem < C::PCH) w_nch = rem; }
+                                else { if (n_wchunk < C::PCH) w_nch = n_wchunk; }
                                 if constexpr (SN_PP_NOBR >= 2) {
                                     // branch-free issue: always the compile-time maximum per wave; an index beyond the piece repeats its last item (same
                                     // bytes, same place), and behind the layer's last piece its first one is fetched into the idle buffer
@@ -1100,10 +1106,12 @@ conv3d_f16_mfma(ConvArgs a)
                             } else if (pre_bridge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             lgkm_wait<0>();
                             static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; ko[j] = ko_n[j]; });
+                            PX_T(1);
                             wg_barrier();
+                            PX_T(2);
                             __builtin_amdgcn_sched_barrier(0);
-                            static_for<0, SEGC>([&](auto jc) {
-                                constexpr int j = decltype(jc)::value, cc = sc * SEGC + j;
+                            static_for<0, SEGC * ((SN_ABL & 4096) ? 2 : 1)>([&](auto jc) {       // (ablation 4096: every burst issued twice - what would a segment of twice the length buy?)
+                                constexpr int j = decltype(jc)::value % SEGC, cc = sc * SEGC + j;
                                 if (SEGC == 1 || cc < nch_p) {
 #pragma unroll
                                     for (int n = 0; n < NF; ++n) {
@@ -1119,11 +1127,18 @@ conv3d_f16_mfma(ConvArgs a)
                                 }
                             });
                             __builtin_amdgcn_sched_barrier(0);
+                            PX_T(3);
                             wg_barrier();
+                            PX_T(4);
+#undef PX_T
+                            if constexpr (SN_TIMING == 1) { t_vm += pxt[1] - pxt[0]; t_bar += pxt[2] - pxt[1]; ++n_piece; }
+                            if constexpr (SN_TIMING == 2) { t_vm += pxt[3] - pxt[2]; t_bar += pxt[4] - pxt[3]; ++n_piece; }
+                            if constexpr (SN_TIMING == 5) { if (t_rel != 0) { t_vm += pxt[0] - t_rel; if (sc == 0) t_bar += pxt[0] - t_rel; } t_rel = pxt[4]; ++n_piece; }      // 5: {gap between segments, of which in front of a piece's first}
                         }
                     });
                     wbi ^= 1;
                 } while (++p < npiece);
+                if constexpr (SN_TIMING == 5) { if (last_slab) t_rel = 0; }
             } else
             if constexpr (PPM) {
                 // ---- PING-PONG K loop (round 3) ------------------------------------------------------------------
