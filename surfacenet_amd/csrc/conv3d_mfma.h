@@ -1056,7 +1056,8 @@ conv3d_f16_mfma(ConvArgs a)
                                     static_for<0, NF>([&](auto nc) {
                                         constexpr int n = decltype(nc)::value;
                                         lds_read128<(cc * NF + n) * C::MFRAG>(wf[j][0][n], wp);
-                                        if constexpr (SPLIT == 1) lds_read128<(cc * NF + n) * C::MFRAG + 1024>(wf[j][1][n], wp);
+                                        if constexpr (SPLIT == 1 && !(SN_ABL & 16384)) lds_read128<(cc * NF + n) * C::MFRAG + 1024>(wf[j][1][n], wp);      // (ablation 16384: no lo-plane weight reads - wrong results, LDS traffic -25 %)
+                                        if constexpr (SPLIT == 1 && (SN_ABL & 16384)) wf[j][1][n] = wf[j][0][n];
                                     });
                                 }
                                 lds_read32<0>(ko_n[j], koff_a + (unsigned)(ch0 + (sc + 1) * SEGC + j) * 16);      // tap offsets of the next segment's chunks
@@ -1094,8 +1095,13 @@ conv3d_f16_mfma(ConvArgs a)
                                 if constexpr (!C::PTAB) { if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, nslab_i, tid, C::NT / 2); }
                             }
                             // the next slab's halo tile: second segment of the slab's first piece (first segment if the piece has only one)
+                            // (tried, A/B r4ae / r4af, profiles/r4/hib_experiment.patch: these DMAs inside the MFMA burst of the slab's first segment instead, one behind every few
+                            // MFMAs - conv1_x / s_conv1_2 -3 %, conv2_x .. conv4_x +3..8 %, similarityNet -2 %: a DMA that waits for the texture path stalls the burst itself)
+                            long long pxh0 = 0, pxh1 = 0, pxh2 = 0;       // SN_TIMING 6: per segment {the vmcnt wait of the load slot, the halo DMA issue}
+                            if constexpr (SN_TIMING == 6) { pxh0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                             if (p == 0 && have_next && !(SN_ABL & 1) && sc == (nseg >= 2 ? 1 : 0))
                                 hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                            if constexpr (SN_TIMING == 6) { pxh1 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                             // (bridge chunk next: it reads the NEXT slab's halo tile - everything this wave has in flight must have landed before the barrier)
                             const bool pre_bridge = bridge_b > 0 && ch0 + sc == nchunk - 2;
                             if (sc == nseg - 1) {
@@ -1104,6 +1110,7 @@ conv3d_f16_mfma(ConvArgs a)
                                 else if (!pre_bridge && p + 1 < npiece && sc == 1 && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
                                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             } else if (pre_bridge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if constexpr (SN_TIMING == 6) { pxh2 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_vm += pxh2 - pxh1; t_bar += pxh1 - pxh0; ++n_piece; }
                             lgkm_wait<0>();
                             static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; ko[j] = ko_n[j]; });
                             PX_T(1);
