@@ -120,6 +120,9 @@
 #ifndef SN_PPX_MINNF
 #define SN_PPX_MINNF 1    // narrowest kernel (cout fragments per workgroup) that takes the ping-pong loop
 #endif
+#ifndef SN_PPX_HALO_SEG0
+#define SN_PPX_HALO_SEG0 1   // f16 / f16x3 ping-pong loop: the next slab's halo DMAs in the slab's FIRST load slot (behind the weight DMAs) instead of its second
+#endif
 #ifndef SN_PPX_SEGC
 #define SN_PPX_SEGC 1     // 2: two K-chunks per ping-pong segment where a chunk is a short burst (MF * NF <= 8: conv1_x)
 #endif
@@ -1099,15 +1102,15 @@ conv3d_f16_mfma(ConvArgs a)
                             // MFMAs - conv1_x / s_conv1_2 -3 %, conv2_x .. conv4_x +3..8 %, similarityNet -2 %: a DMA that waits for the texture path stalls the burst itself)
                             long long pxh0 = 0, pxh1 = 0, pxh2 = 0;       // SN_TIMING 6: per segment {the vmcnt wait of the load slot, the halo DMA issue}
                             if constexpr (SN_TIMING == 6) { pxh0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-                            if (p == 0 && have_next && !(SN_ABL & 1) && sc == (nseg >= 2 ? 1 : 0))
+                            if (p == 0 && have_next && !(SN_ABL & 1) && sc == ((nseg >= 2 && !SN_PPX_HALO_SEG0) ? 1 : 0))
                                 hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
                             if constexpr (SN_TIMING == 6) { pxh1 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                             // (bridge chunk next: it reads the NEXT slab's halo tile - everything this wave has in flight must have landed before the barrier)
                             const bool pre_bridge = bridge_b > 0 && ch0 + sc == nchunk - 2;
                             if (sc == nseg - 1) {
                                 // the next weight piece has landed; halo DMAs issued in THIS load segment may still fly unless the slab ends here
-                                if (!pre_bridge && p + 1 < npiece && sc == 1 && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
-                                else if (!pre_bridge && p + 1 < npiece && sc == 1 && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
+                                if (!pre_bridge && p + 1 < npiece && (sc == 1 || SN_PPX_HALO_SEG0) && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
+                                else if (!pre_bridge && p + 1 < npiece && (sc == 1 || SN_PPX_HALO_SEG0) && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
                                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             } else if (pre_bridge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             if constexpr (SN_TIMING == 6) { pxh2 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_vm += pxh2 - pxh1; t_bar += pxh1 - pxh0; ++n_piece; }
