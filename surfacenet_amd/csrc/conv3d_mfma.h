@@ -154,7 +154,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMaxSlab = 48;
+constexpr int kMaxSlab = 128;
 
 struct ConvArgs {
     const _Float16 *in;   // [B][in_cs/8][D][D][D][8]  (hi plane; lo plane at +in_lo_off elements when SPLIT)

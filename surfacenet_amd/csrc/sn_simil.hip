@@ -27,7 +27,20 @@ static int simil_cs8(int mode) { return mode == 0 ? 4 : 2; }
 // the last conv of every block writes the 2x2 max-pooled map directly (EPI_POOL2D): the unpooled map is never stored
 #define SCONVP 3, 1, 4, kSimNF, EPI_POOL2D, SP, SIMCS8, SIMPCH, 8, 0, 1
 #define SCONV5P 3, 1, 2, 8, EPI_POOL2D, SP, 2, 2, 8, 0, 2
-static int simil_nf(int i) { return kSimStage[i] == 4 ? 8 : kSimNF; }
+// SN_SIM_NF8 (round 4): 128 output channels per workgroup with ONE-group channel slabs for the f16x3 layers with >= 128 outputs (two-group slabs + 128-channel weight pieces
+// would need 169 KB of LDS): half the halo DMAs per MFMA, a slab boundary every 2.25 chunks. Same-box (profiles/r4/ab_r4ak_nf8.log): s_conv2_1 -6 %, s_conv3_x -2..5 %, s_conv4_x
+// -3..6 %, s_conv2_2 (pooled, 128 outputs) +5 % -> not that one; similarityNet +2.5 % patches/s. 0: every layer on the 64-channel kernels; 1: unpooled layers only.
+#ifndef SN_SIM_NF8
+#define SN_SIM_NF8 2
+#endif
+#define SCONV8 3, 1, 4, 8, EPI_STORE, SP, 1, 2, 8, 0, 1
+#define SCONV8P 3, 1, 4, 8, EPI_POOL2D, SP, 1, 2, 8, 0, 1
+static bool simil_wide(int i, int mode)
+{
+    const bool last = (i == 12 || kSimStage[i + 1] != kSimStage[i]);
+    return SN_SIM_NF8 && mode == 1 && kSimStage[i] < 4 && kSimC[i + 1] >= 128 && (!last || (SN_SIM_NF8 >= 2 && kSimC[i + 1] >= 256));
+}
+static int simil_nf(int i, int mode = 0) { return kSimStage[i] == 4 || simil_wide(i, mode) ? 8 : kSimNF; }
 
 static int simil_mode(sn_ctx *c) { return c->split == 0 ? 0 : 1; }   // f16m8 contexts run this net in f16x3 (own workspace)
 
@@ -46,7 +59,7 @@ static int simil_pack(sn_ctx *c)
         L.bridge = (want == 1 && !no_bridge) ? 1 : 0;       // f16x3: two-group slabs = 4.5 K-chunks -> 9 chunks per slab pair (pack_conv_host decides per layer)
         const float *W = c->simil_host.data() + c->simil_descs[2 * i].offset, *b = c->simil_host.data() + c->simil_descs[2 * i + 1].offset;
         std::vector<float> one((size_t)L.cout, 1.f), zero((size_t)L.cout, 0.f);
-        if ((rc = pack_conv(c, L, W, b, one.data(), zero.data(), one.data(), simil_nf(i), L.cout / (16 * simil_nf(i)), kSimStage[i] == 4 ? 2 : simil_cs8(want), want)) != SN_OK) return rc;
+        if ((rc = pack_conv(c, L, W, b, one.data(), zero.data(), one.data(), simil_nf(i, want), L.cout / (16 * simil_nf(i, want)), kSimStage[i] == 4 ? 2 : (simil_wide(i, want) ? 1 : simil_cs8(want)), want)) != SN_OK) return rc;
     }
     c->simil_split = want;
     return SN_OK;
@@ -142,6 +155,11 @@ static int run_simil_t(sn_ctx *c, const SimilWs &w, int n)
         const bool last = (i == 12 || kSimStage[i + 1] != st);
         if (last) {      // conv + bias + ReLU + Pool2DLayer(2) in one kernel
             Act out = w.pool[st];
+            bool done = false;
+            if constexpr (SN_SIM_NF8 >= 2 && SP == 1) {
+                if (simil_wide(i, 1)) { rc = launch_conv<SCONV8P>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n); done = true; }
+            }
+            if (!done)
             rc = st == 4 ? launch_conv<SCONV5P>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n)
                          : launch_conv<SCONVP>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
             if (rc != SN_OK) return rc;
@@ -150,6 +168,14 @@ static int run_simil_t(sn_ctx *c, const SimilWs &w, int n)
         }
         Act out = w.a[st][flip[st]];
         flip[st] ^= 1;
+        if constexpr (SN_SIM_NF8 && SP == 1) {
+            if (simil_wide(i, 1)) {
+                rc = launch_conv<SCONV8>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
+                if (rc != SN_OK) return rc;
+                cur = out; cur_cs = kSimC[i + 1];
+                continue;
+            }
+        }
         rc = st == 4 ? launch_conv<SCONV5>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n)
                      : launch_conv<SCONV>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
         if (rc != SN_OK) return rc;
