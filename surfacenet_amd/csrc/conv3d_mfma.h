@@ -1016,8 +1016,8 @@ conv3d_f16_mfma(ConvArgs a)
                 const unsigned xslab = xbuf_a + xb * C::XBUF;
                 constexpr int NPLM = C::NPLM;
                 int ko[SEGC], ko_n[SEGC];
-                int bridge_o = 0, bridge_b = 0;                     // bridge chunks (write_koff_part): units this slab's last chunk takes from the next slab
-                bridge_o = su_o; bridge_b = su_b;
+                const int bridge_b = su_b;                          // bridge chunks (write_koff_part): units this slab's last chunk takes from the next slab
+                // (tried, A/B r4am: a slab's first tap offset read in the previous slab's last load slot instead of by an LDS round trip at the head of the slab - no change)
                 static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_read32<j * 16>(ko[j], koff_a); ko_n[j] = 0; });
                 lgkm_wait<0>();
                 int p = 0;
