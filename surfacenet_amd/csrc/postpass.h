@@ -12,8 +12,9 @@
 //   that cell's voxel gets one vote per occurrence of the view in the cube's pair list  (:252-255)
 //   all-zero pixel: argmax = column 0 = the view's minimum bin; its cell's voxel, or voxel 0 if that cell is empty.
 // One workgroup = one (cube, pair-list entry); entries that repeat an earlier view of the same cube exit at once, the
-// first occurrence votes with the view's multiplicity. Two open-addressing hash tables per workgroup live in a global
-// workspace (L2-resident at s=32: <= 2 MB/workgroup), sized 2x the selected voxel count:
+// first occurrence votes with the view's multiplicity. Two open-addressing hash tables per workgroup, sized 2x the selected voxel count -
+// in LDS when at most RP_LDS_M voxels are selected (round 4: the realistic case - ~1,700 of a 32^3 cube at the bench's threshold; every
+// insert / max / lookup is then an LDS atomic instead of a round trip to L2), else in a global workspace (<= 2 MB/workgroup):
 //   pixel table  key = (w,h) as 2 x int32            value = packed best (pred bits << 32 | ~relative depth)
 //   cell table   key = (pixel slot, d)               value = max flat voxel index
 // Using the pixel's slot in the cell key keeps both keys 64-bit for arbitrary int32 pixel coordinates.
@@ -27,6 +28,13 @@ namespace sn {
 
 constexpr int RP_NT = 1024;
 constexpr int RP_LIST = 8192;        // selected voxels of a (cube, view) listed in LDS (2 x 32 KB)
+constexpr int RP_LDS_M = 3400;       // ... up to this many (10 % of a 32^3 cube), the hash tables live in LDS as well: capacity RP_LDS_CAP, load factor <= 0.83
+constexpr int RP_LDS_CAP = 4096;
+constexpr int RP_LDS_Q = 14336, RP_LDS_TAB = 28672;
+static_assert(RP_LDS_M * 4 <= RP_LDS_Q && RP_LDS_Q + RP_LDS_M * 4 <= RP_LDS_TAB && RP_LDS_M <= RP_LIST && RP_LDS_M * 6 <= RP_LDS_CAP * 5, "ray_pool_kernel LDS map");
+// LDS map: [0, 32 K) list of selected voxels (RP_LIST entries; with LDS tables only the first RP_LDS_M are in use), then either the cell slots of all
+// RP_LIST voxels [32 K, 64 K) or - LDS tables - the cell slots of RP_LDS_M voxels [14 K, 28 K) and the four tables [28 K, 28 K + 28 B x RP_LDS_CAP)
+constexpr int RP_LDS_BYTES = RP_LDS_TAB + RP_LDS_CAP * 28 > 2 * RP_LIST * 4 ? RP_LDS_TAB + RP_LDS_CAP * 28 : 2 * RP_LIST * 4;
 constexpr unsigned long long RP_EMPTY = ~0ull;
 constexpr unsigned RP_NONE = 0xFFFFFFFFu;
 
@@ -52,33 +60,48 @@ __device__ __forceinline__ unsigned rp_hash(unsigned long long k, unsigned mask)
 }
 
 // insert-or-find; returns the slot. Table entries start as RP_EMPTY.
-__device__ __forceinline__ unsigned rp_insert(unsigned long long *keys, unsigned mask, unsigned long long k)
+// The tables live in LDS or in global memory; the helpers are templates over the pointer type so that each instantiation addresses ONE address space
+// (with generic pointers every access becomes a flat instruction behind a full s_waitcnt, and the lock-step passes below serialise again).
+typedef __attribute__((address_space(3))) unsigned long long rp_lds_u64;
+typedef __attribute__((address_space(3))) unsigned rp_lds_u32;
+template <typename P>
+__device__ __forceinline__ auto rp_ld(P p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename P>
+__device__ __forceinline__ unsigned long long rp_cas(P p, unsigned long long expected, unsigned long long desired)
+{
+    __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expected;            // the value found (== the old `expected` on success)
+}
+template <typename P, typename T>
+__device__ __forceinline__ void rp_max(P p, T v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// insert-or-find; returns the slot. Table entries start as RP_EMPTY.
+template <typename P>
+__device__ __forceinline__ unsigned rp_insert(P keys, unsigned mask, unsigned long long k)
 {
     unsigned h = rp_hash(k, mask);
     for (;;) {
-        unsigned long long cur = __hip_atomic_load(keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long cur = rp_ld(keys + h);
         if (cur == k) return h;
         if (cur == RP_EMPTY) {
-            unsigned long long prev = atomicCAS(keys + h, RP_EMPTY, k);
+            unsigned long long prev = rp_cas(keys + h, RP_EMPTY, k);
             if (prev == RP_EMPTY || prev == k) return h;
         }
         h = (h + 1) & mask;
     }
 }
 
-__device__ __forceinline__ bool rp_find(const unsigned long long *keys, unsigned mask, unsigned long long k)
+template <typename P>
+__device__ __forceinline__ bool rp_find(P keys, unsigned mask, unsigned long long k)
 {
     unsigned h = rp_hash(k, mask);
     for (;;) {
-        unsigned long long cur = __hip_atomic_load(keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long cur = rp_ld(keys + h);
         if (cur == k) return true;
         if (cur == RP_EMPTY) return false;
         h = (h + 1) & mask;
     }
 }
-
-template <typename T>
-__device__ __forceinline__ T rp_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ void rp_vote(uint8_t *votes, unsigned i, unsigned mult)
 {
@@ -120,12 +143,39 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
     // ---- pass 1: count the selected voxels and list them (any order: every later step is a max / an add). With the list (up to
     // RP_LIST voxels, i.e. every realistic surface) the passes below touch only the selected voxels with all lanes busy; without it
     // a wave runs the fp64 projection whenever ANY of its 64 lanes holds a selected voxel - 32 times per lane at 1 % selected as at 10 %.
-    __shared__ unsigned sh_list[RP_LIST], sh_q[RP_LIST];
-    // 2 x 32 KiB + sh_i: more than the 64 KiB of LDS a workgroup gets on CDNA1-3 - this library is built for gfx950 only (Makefile: 160 KiB per
-    // CU, and the 1024-thread workgroup owns its CU anyway). Halve RP_LIST before retargeting.
-    static_assert(sizeof(sh_list) + sizeof(sh_q) + 64 <= 160 * 1024, "ray_pool_kernel's selected-voxel list exceeds gfx950's LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char sh_mem[RP_LDS_BYTES];
+    unsigned *const sh_list = reinterpret_cast<unsigned *>(sh_mem);
+    // more than the 64 KiB of LDS a workgroup gets on CDNA1-3 - this library is built for gfx950 only (Makefile: 160 KiB per
+    // CU, and the 1024-thread workgroup owns its CU anyway). Halve RP_LIST / RP_LDS_M before retargeting.
+    static_assert(RP_LDS_BYTES + 64 <= 160 * 1024, "ray_pool_kernel's lists and tables exceed gfx950's LDS");
     if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0x7fffffff; sh_i[2] = 0; }
     __syncthreads();
+    // (eight 16-byte loads per thread in flight at once: one load per thread and iteration, each waited for before the next, made this scan of a
+    // 128 KB cube ~100 us - 32 dependent memory round trips - i.e. most of the kernel at realistic selection rates)
+    if ((V3 & 3) == 0 && (reinterpret_cast<size_t>(pred) & 15) == 0) {
+        for (int base = 0; base < V3; base += 8 * 4 * RP_NT) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i4 = base + (k * RP_NT + tid) * 4;
+                v[k] = i4 < V3 ? *reinterpret_cast<const float4 *>(pred + i4) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i4 = base + (k * RP_NT + tid) * 4;
+                if (i4 >= V3) continue;
+                const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const _Float16 p = (_Float16)e[j];
+                    if (!a.use_thresh || p > thr) {
+                        const int pos = atomicAdd(&sh_i[0], 1);
+                        if (pos < RP_LIST) sh_list[pos] = (unsigned)(i4 + j);
+                    }
+                }
+            }
+        }
+    } else
     for (int i = tid; i < V3; i += RP_NT) {
         _Float16 p;
         if (selected(i, p)) {
@@ -140,19 +190,24 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
     const int n_it = listed ? m : V3;                       // iteration space of passes 3-5: list positions, or all voxels
     unsigned cap = 64;
     while (cap < 2u * (unsigned)m) cap <<= 1;
+    if (m <= RP_LDS_M && cap > (unsigned)RP_LDS_CAP) cap = RP_LDS_CAP;       // (LDS tables: a fuller table instead of a global one)
     const unsigned mask = cap - 1;
 
     const size_t wg = (size_t)cube * E + entry;
-    unsigned long long *pix_key = a.pix_key + wg * a.cap_max, *pix_best = a.pix_best + wg * a.cap_max;
-    unsigned long long *cell_key = a.cell_key + wg * a.cap_max;
-    unsigned *cell_idx = a.cell_idx + wg * a.cap_max;
+    const bool lds_tables = m <= RP_LDS_M;                  // (uniform across the workgroup; implies `listed`)
     unsigned *cslot = a.cslot + wg * V3;
+    unsigned *const sh_q = reinterpret_cast<unsigned *>(sh_mem + (lds_tables ? RP_LDS_Q : RP_LIST * 4));
+    uint8_t *votes = a.votes + (size_t)cube * V3;
 
+    // passes 2-5 over one set of tables (instantiated for LDS and for global tables)
+    auto body = [&](auto pix_key, auto pix_best, auto cell_key, auto cell_idx) {
     // ---- pass 2: clear the part of the tables this workgroup uses
     for (unsigned i = tid; i < cap; i += RP_NT) { pix_key[i] = RP_EMPTY; pix_best[i] = 0; cell_key[i] = RP_EMPTY; cell_idx[i] = 0; }
     __syncthreads();
 
     // ---- pass 3: project, insert pixel and cell, keep the largest voxel index per cell
+    // (measured and dropped, round 4: all of a thread's items advanced in lock-step, their k-th table accesses issued together - no faster with global tables,
+    // slower with LDS tables; plain L1-cached probe loads with acquire fences between the passes - slower)
     int dmin_t = 0x7fffffff;
     for (int j = tid; j < n_it; j += RP_NT) {
         const int i = listed ? (int)sh_list[j] : j;
@@ -175,7 +230,7 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
                 const int wi = (int)w, hi = (int)h, di = (int)d;
                 const unsigned ps = rp_insert(pix_key, mask, ((unsigned long long)((unsigned)wi ^ 0x80000000u) << 32) | ((unsigned)hi ^ 0x80000000u));
                 q = rp_insert(cell_key, mask, ((unsigned long long)ps << 32) | (unsigned)di);
-                atomicMax(cell_idx + q, (unsigned)i);
+                rp_max(cell_idx + q, (unsigned)i);
                 dmin_t = min(dmin_t, di);
             }
         }
@@ -199,12 +254,11 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
         const _Float16 p = (_Float16)pred[i];
         if (!(p > (_Float16)0.f)) continue;                 // a stored 0 is indistinguishable from an empty cell
         const unsigned long long ck = rp_ld(cell_key + q);
-        atomicMax(pix_best + (unsigned)(ck >> 32), packed_of(p, (int)(unsigned)ck));
+        rp_max(pix_best + (unsigned)(ck >> 32), packed_of(p, (int)(unsigned)ck));
     }
     __syncthreads();
 
     // ---- pass 5: winners vote
-    uint8_t *votes = a.votes + (size_t)cube * V3;
     for (int j = tid; j < n_it; j += RP_NT) {
         const int i = listed ? (int)sh_list[j] : j;
         const unsigned q = listed ? sh_q[j] : cslot[i];
@@ -224,6 +278,12 @@ __global__ void __launch_bounds__(RP_NT) ray_pool_kernel(RayPoolArgs a)
         if (target > 0) rp_vote(votes, (unsigned)target, mult);
         else if (target == 0) sh_i[2] = 1;                  // several pixels may elect voxel 0: count it once
     }
+    };
+    if (lds_tables) {
+        rp_lds_u64 *const t = (rp_lds_u64 *)(sh_mem + RP_LDS_TAB);            // (C-style casts: generic -> LDS address space)
+        body(t, t + RP_LDS_CAP, t + 2 * RP_LDS_CAP, (rp_lds_u32 *)(t + 3 * RP_LDS_CAP));
+    } else
+        body(a.pix_key + wg * a.cap_max, a.pix_best + wg * a.cap_max, a.cell_key + wg * a.cap_max, a.cell_idx + wg * a.cap_max);
     __syncthreads();
     if (tid == 0 && sh_i[2]) rp_vote(votes, 0u, mult);
 }
