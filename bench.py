@@ -441,7 +441,8 @@ def main():
         except Exception:
             pass
         out["roofline"]["note"] = ("achieved = ALGORITHMIC conv FLOPs / kernel time; the f16x3 mode issues 3 MFMA FLOPs per algorithmic "
-                                   "FLOP (1.5 in the two merge layers, whose correction terms run on the MX-scaled fp6 MFMA at twice the fp16 rate), so its ceiling is frac = 1/3 .. 2/3" if args.precision.startswith("f16x3") else "achieved = algorithmic conv FLOPs / kernel time")
+                                   "FLOP (1.5 in the two merge layers, whose correction terms run on the MX-scaled fp6 MFMA at twice the fp16 rate), so its ceiling is frac = 1/3 .. 2/3; peak = the nominal 2.5 PF at 2.4 GHz - a pure 16x16x32 MFMA stream sustains "
+                                   "1,950-1,980 TF at 1.87 GHz on this chip (tools/probe/power_probe.hip, profiles/r4/power_probe_r4.txt)" if args.precision.startswith("f16x3") else "achieved = algorithmic conv FLOPs / kernel time")
         if world == 1 and args.precision == "f16x3" and not args.no_fast_mode:
             out["fast_mode_f16"] = fast_mode(surfacenet_amd, scene, values, s, n, n_vp, local_rank, max(3, args.steps // 2))
         if world == 1 and s == 32 and not args.no_s64:
