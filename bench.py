@@ -277,20 +277,23 @@ def main():
     if os.environ.get("BENCH_ZERO_DATA"):   # DVFS experiment only: all-zero operands draw less power
         values = [np.zeros_like(v) if (v.ndim == 5 and v.shape[2] == 3 and v.shape[0] != 1) else v for v in values]
         scene["imgs"] = [np.zeros_like(im) for im in scene["imgs"]]
-    ctx = surfacenet_amd.Context(cube_D=s, max_samples=n * n_vp, device=local_rank, precision=args.precision)
-    ctx.load_param_values(values)
-    ctx.set_cameras(scene["cams"])
-    ctx.set_images(scene["imgs"])
-    d_pairs, d_xyz, d_resol, d_w = (ctx.upload(scene[k]) for k in ("pairs", "xyz", "resol", "w"))
+    def make_ctx():
+        c = surfacenet_amd.Context(cube_D=s, max_samples=n * n_vp, device=local_rank, precision=args.precision)
+        c.load_param_values(values)
+        c.set_cameras(scene["cams"])
+        c.set_images(scene["imgs"])
+        return (c,) + tuple(c.upload(scene[k]) for k in ("pairs", "xyz", "resol", "w"))
+    ctx, d_pairs, d_xyz, d_resol, d_w = make_ctx()
     native = use_dist and not (args.torch_comm or bool(os.environ.get("BENCH_TORCH_COMM")))
-    comm_note, native_hung = None, False
+    comm_note, native_hung, rccl_info = None, False, None
     if native:
-        # the C ABI's own exchange: rank 0 draws the RCCL unique id, torch.distributed ships its 128 bytes, every rank joins; then one small
-        # all-gather through the library is compared with torch.distributed's. Any failure on any rank -> every rank falls back to torch.
-        # The set-up runs in a helper thread with a deadline: a communicator that never forms (the binding has only ever met a one-rank group on
-        # the builder's boxes) must cost a note in the JSON line, not the scaling run.
+        # the C ABI's own exchange: rank 0 draws the RCCL unique id, torch.distributed ships its 128 bytes, every rank joins (sn_comm_init_deadline:
+        # the library bounds the wait itself); then one small all-gather through the library is checked against known data. Any failure on any
+        # rank -> every rank falls back to torch. The probe all-gather runs in a helper thread with the same deadline: a collective that never
+        # completes (the binding has only ever met a one-rank group on the builder's boxes) must cost a note in the JSON line, not the scaling
+        # run - and a context whose helper thread is still inside the library is ABANDONED (a fresh one carries the torch path).
         import threading
-        state = {"ok": 0, "why": "native communicator set-up did not finish within %d s" % NATIVE_COMM_DEADLINE_S}
+        state = {"ok": 0, "why": "native all-gather probe did not finish within %d s" % NATIVE_COMM_DEADLINE_S}
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             try:
@@ -299,35 +302,47 @@ def main():
                 state["why"] = "%s: %s" % (type(e).__name__, e)
         dist.broadcast(uid, src=0)
         uid_bytes = bytes(uid.cpu().numpy().tobytes())
+        try:
+            rccl_info = surfacenet_amd.Context.comm_info()
+        except Exception as e:      # noqa: BLE001
+            rccl_info = ("unavailable: %s" % e, 0)
+        joined = False
+        try:
+            ctx.comm_init(world, rank, uid_bytes, timeout_s=NATIVE_COMM_DEADLINE_S)
+            joined = True
+        except Exception as e:      # noqa: BLE001 - whatever went wrong, the scaling run must still produce a number
+            state["why"] = "%s: %s" % (type(e).__name__, e)
 
-        def _native_setup():
+        def _native_probe(c):
             try:
                 torch.cuda.set_device(local_rank)
-                ctx.comm_init(world, rank, uid_bytes)
                 probe = (np.arange(4096, dtype=np.float32) + 10000.0 * rank)
-                d_p, d_pg = ctx.upload(probe), ctx.dev_alloc(world * probe.nbytes)
-                ctx.allgather_f32_dev_overlap(d_p, probe.size, d_pg, 7)
-                ctx.synchronize()
+                d_p, d_pg = c.upload(probe), c.dev_alloc(world * probe.nbytes)
+                c.allgather_f32_dev_overlap(d_p, probe.size, d_pg, 7)
+                c.synchronize()
                 got = np.empty((world * probe.size,), np.float32)
-                ctx.d2h(got, d_pg)
+                c.d2h(got, d_pg)
                 want = np.concatenate([np.arange(4096, dtype=np.float32) + 10000.0 * r for r in range(world)])
-                ctx.dev_free(d_p); ctx.dev_free(d_pg)
+                c.dev_free(d_p); c.dev_free(d_pg)
                 if np.array_equal(got, want):
                     state["ok"] = 1
                 else:
                     state["why"] = "native all-gather returned wrong data"
-            except Exception as e:      # noqa: BLE001 - whatever went wrong, the scaling run must still produce a number
+            except Exception as e:      # noqa: BLE001
                 state["why"] = "%s: %s" % (type(e).__name__, e)
 
-        th = threading.Thread(target=_native_setup, daemon=True)
-        th.start()
-        th.join(NATIVE_COMM_DEADLINE_S)
-        native_hung = th.is_alive()
+        if joined:
+            th = threading.Thread(target=_native_probe, args=(ctx,), daemon=True)
+            th.start()
+            th.join(NATIVE_COMM_DEADLINE_S)
+            native_hung = th.is_alive()
         ok, why = (0 if native_hung else state["ok"]), state["why"]
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             native, comm_note = False, "native RCCL binding unavailable (%s): torch.distributed all-gather instead" % (why or "another rank failed")
+            if native_hung:
+                ctx, d_pairs, d_xyz, d_resol, d_w = make_ctx()     # the old context belongs to the stuck thread now: never touched again
     if native:
         d_fused = [ctx.dev_alloc(n * s3 * 4) for _ in range(2)]
         d_all = [ctx.dev_alloc(world * n * s3 * 4) for _ in range(2)]
@@ -409,7 +424,8 @@ def main():
             "config": {"workload": "synthetic 2-view 1600x1200, s=%d, batch=%d cubes/GPU, N_viewpair=%d (%s)" % (
                 s, n, n_vp, "BASELINE.json configs[1]" if (s, n, n_vp) == (32, 64, 2) else ("one GPU's shard of BASELINE.json configs[3]: s=64, 256 cubes over 8 GPUs" if (s, n) == (64, 32) else "non-default workload")),
                        "cubes_per_gpu": n, "samples_per_step": n * n_vp * world, "parallelism": "cube-sharded x%d%s" % (world, (", RCCL all-gather of fused probabilities" + (" (native sn_allgather_f32_dev_overlap)" if native else " (torch.distributed)")) if world > 1 else ""),
-                       **({"comm_note": comm_note} if comm_note else {})},
+                       **({"comm_note": comm_note} if comm_note else {}),
+                       **({"rccl": {"file": rccl_info[0], "version_code": rccl_info[1]}} if rccl_info else {})},
             "roofline": {"bound": "mfma", "kernel": "conv3d_f16_mfma<%s>" % dom, "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                          "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
@@ -449,6 +465,8 @@ def main():
             out["s64"] = s64_mode(surfacenet_amd, values, n_vp, local_rank, max(3, args.steps // 2), args.precision)
         if world == 1 and not args.no_post_pass:
             out["loop_body_with_post_pass"] = post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, max(3, args.steps // 2))
+            # the regime of a trained net: ~1 % of the centre crop selected (a thin surface) - ray pooling then keeps its hash tables in LDS
+            out["loop_body_with_post_pass_thin_surface"] = post_pass(surfacenet_amd, ctx, scene, s, n, n_vp, max(3, args.steps // 2), keep_frac=0.01)
         if world == 1 and not args.no_simil:
             out["similarity_net"] = simil_net(surfacenet_amd, ctx, scene, max(2, args.steps // 3))
         if world == 1 and s == 32 and not args.no_scenes:

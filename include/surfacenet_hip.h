@@ -221,8 +221,9 @@ SN_API int sn_project_points(sn_ctx *ctx, int V, const double *P, int n, const d
  * The two merge layers read their inputs as fp16 + 6-bit e2m3 codes scaled by a per-tensor premultiplier 2^s ("cat": the concat buffer of
  * sigmoid side outputs; "act": merge_conv_a's ReLU output). s is static - sized from the layers' BatchNorm parameters, which trained nets obey
  * (nets/SurfaceNet.py:33-74, every batch_norm) - unless the caller calibrates it on data:
- *   sn_calibrate_dev looks at the activations the LAST forward call left in the workspace (n_samples of them; run sn_forward / sn_cvc_forward on a
- *   representative batch first), and sets each tensor's s to the largest value whose saturated fraction (|v| * 2^s > 7.5) stays <= max_sat_fraction.
+ *   sn_calibrate_dev looks at the activations the LAST forward call left in the workspace (n_samples of them, <= 0: all that call ran; run
+ *   sn_forward / sn_cvc_forward on a representative batch first - SN_ERR_STATE when none has run since the weights / the mode were set, or when it
+ *   ran fewer samples; default precision mode only), and sets each tensor's s to the largest value whose saturated fraction (|v| * 2^s > 7.5) stays <= max_sat_fraction.
  *   The new exponents apply to every later call of this context; sn_load_weights / sn_set_precision restore the static ones.
  * A value beyond the code range loses (only) its own correction term; it is not an error. sn_numeric_status reports - and clears - the WARNING bits:
  * which layers stored such values since the last call (names: comma-separated layer names, bit i = the i-th). */
@@ -240,6 +241,13 @@ SN_API int sn_numeric_status(sn_ctx *ctx, unsigned *saturated_bits, char *names,
  * sn_comm_init (collective). sn_allgather_f32_dev is asynchronous on the context's stream. */
 SN_API int sn_comm_unique_id(char *id128);
 SN_API int sn_comm_init(sn_ctx *ctx, int world, int rank, const char *id128);
+/* The same with a bound on the wait (ncclCommInitRank blocks until EVERY rank has called it): after timeout_s seconds the call returns
+ * SN_ERR_COMM, the context stays without a communicator and remains usable for everything but the exchange (the helper thread that is still
+ * inside RCCL is abandoned). timeout_s <= 0: no deadline (= sn_comm_init; the caller vouches that all ranks arrive). */
+SN_API int sn_comm_init_deadline(sn_ctx *ctx, int world, int rank, const char *id128, double timeout_s);
+/* Which RCCL the entry points are bound to: file name + whether the host process had it mapped already (then that copy is used: a process
+ * must not run two RCCL copies) and the ncclGetVersion code. Loads librccl if nothing has yet. */
+SN_API int sn_comm_info(char *file, int file_cap, int *version_code);
 SN_API int sn_allgather_f32_dev(sn_ctx *ctx, const float *local_dev, size_t n_local, float *global_dev);
 /* The same on the context's own communication stream, ordered behind everything submitted to the kernel stream so far: the all-gather of
  * batch i overlaps the kernels of batch i + 1. slot (0..7) names its completion; sn_comm_wait(ctx, slot) makes the kernel stream wait for it
@@ -249,7 +257,10 @@ SN_API int sn_comm_wait(sn_ctx *ctx, int slot);
 /* Variable-length all-gather of bytes - the exchange of the packed sparse voxel lists of a sharded scene (SURVEY §8e "counts then
  * all-gather-v"; utils/sparseCubes.py:9-77 produces the lists, main_reconstruct.py:153-160 accumulates them): every rank contributes
  * n_local bytes of device memory (0 allowed, different per rank); global_dev receives the contributions back to back in rank order and
- * counts[r] (host, `world` entries) their sizes. Synchronous. SN_ERR_ARG with counts[] filled when global_cap is too small. */
+ * counts[r] (host, `world` entries) their sizes. Synchronous. Every rank issues the same two collectives whatever its own arguments are: a
+ * destination that cannot hold the total is reported AFTER the payload all-gather (SN_ERR_ARG, counts[] filled in) and must NOT be answered by
+ * a retry of this rank alone. Size the destination first with sn_allgatherv_counts (collective: the 8-byte counts all-gather alone). */
+SN_API int sn_allgatherv_counts(sn_ctx *ctx, size_t n_local, unsigned long long *counts);
 SN_API int sn_allgatherv_bytes_dev(sn_ctx *ctx, const void *local_dev, size_t n_local, void *global_dev, size_t global_cap,
                                    unsigned long long *counts);
 

@@ -23,13 +23,25 @@ the device's error, correlation 0.82 between the two error fields) is this sensi
 tried (premultipliers, lo exponent, block shape, renormalisation on / off) lowers the correlation.
 mode "f16x3" (the default): everything "x3" except the concat buffer and merge_conv_a's output (storage m6, premultipliers s = 2 / 0)
 and merge_conv_a / merge_conv_b (product m6); conv1_3 / conv2_3 feed their side conv and pool from unrounded registers.
-mode "f16m8": every tensor m6, every conv product m6 (the network input with s = -5)."""
+mode "f16m8": every tensor m6, every conv product m6 (the network input with s = -5).
+Round 5: a per-layer CORRECTION-FORMAT TABLE for the default mode (`table`, layer name -> "x3" | "m6" | "m8"; LAYER_FORMATS_DEFAULT is what
+the library ships) answers "which 3x3x3 layers may leave the three-fp16-MFMA arithmetic at an unchanged tolerance" without a GPU:
+  * "m8": the same two-term correction as "m6" on fp8 e4m3 codes (2 MFMA units per product instead of 1.5 / 3): q8 = e4m3, round to nearest
+    even, saturating at 448, subnormal step 2^-9; lo parts premultiplied by 2^12; the same 32-element weight blocks with one power-of-two scale
+    (block maximum in (224, 448]); activations with a static premultiplier 2^s8 (default 0).
+  A tensor is stored in the format its 3x3x3 reader asks for (plus the fp16 lo plane where a 1x1x1 side convolution reads it as well)."""
 import numpy as np
 
 from oracle import net_oracle
 
 LO_EXP = 11
+LO_EXP8 = 12
 S_ACT, S_CAT, S_X0 = 0, 2, -5
+S8_ACT = 0
+# correction format per 3x3x3 layer in the default ("f16x3") mode, as shipped: x3 = three fp16 MFMAs, m6 = fp6 e2m3 MX step, m8 = fp8 e4m3 MX step
+LAYER_FORMATS_DEFAULT = {"conv1_1": "x3", "conv1_2": "x3", "conv1_3": "x3", "conv2_1": "x3", "conv2_2": "x3", "conv2_3": "x3",
+                         "conv3_1": "x3", "conv3_2": "x3", "conv3_3": "x3", "conv4_1": "x3", "conv4_2": "x3", "conv4_3": "x3",
+                         "merge_conv_a": "m6", "merge_conv_b": "m6"}
 
 
 def _ilogb(a):
@@ -43,13 +55,17 @@ def _ilogb(a):
     return out
 
 
-def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
+def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act=S8_ACT, s6_of=None):
     import torch
     import torch.nn.functional as F
     assert mode in ("f16x3", "f16m8")
     td = torch.float64
     P = net_oracle.params_to_dict(values)
     full = mode == "f16m8"
+    fmt_of = dict(LAYER_FORMATS_DEFAULT)
+    if table:
+        assert not full and set(table) <= set(fmt_of) and set(table.values()) <= {"x3", "m6", "m8"}, table
+        fmt_of.update(table)
 
     def f16(t):
         return t.to(torch.float16).to(td)
@@ -60,20 +76,48 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
         step = torch.where(a < 2, torch.full_like(a, 0.125), torch.where(a < 4, torch.full_like(a, 0.25), torch.full_like(a, 0.5)))
         return torch.sign(v) * torch.round(a / step) * step
 
-    class T:  # a stored activation tensor in ORIGINAL units + how the device holds it
-        def __init__(self, v, oe, fmt, s):
-            self.oe = torch.from_numpy(np.asarray(oe, dtype=np.float64)).view(1, -1, 1, 1, 1)      # stored = v * 2^oe
-            r = v * torch.exp2(self.oe)
-            self.hi = f16(r)
-            if fmt == "x3":
-                self.lo = f16(r - self.hi)
-            else:
-                self.lo = q6((r - self.hi) * 2.0 ** (LO_EXP + s)) / 2.0 ** (LO_EXP + s)
-            self.fmt, self.s = fmt, s
-            self.v = (self.hi + self.lo) / torch.exp2(self.oe)                                         # what a reader reconstructs
+    def q8(v):
+        """fp8 e4m3 (OCP e4m3fn) of v: RNE, saturating at 448, subnormal step 2^-9 below 2^-6."""
+        a = v.abs().clamp(max=448.0)
+        e = torch.floor(torch.log2(torch.clamp(a, min=2.0 ** -6)))
+        e = e + (torch.exp2(e + 1) <= a).to(td) - (torch.exp2(e) > torch.clamp(a, min=2.0 ** -6)).to(td)       # (log2 rounding at exact powers of two)
+        step = torch.exp2(e - 3)
+        return (torch.sign(v) * torch.round(a / step) * step).clamp(min=-448.0, max=448.0)
 
-    def block_q6(wh, wl, kind, cin):
-        """wh, wl*2^11: (O, Cp, T) renormalised weights, Cp = cin padded to 8. -> their 6-bit block-scaled values."""
+    QF = {"m6": (q6, LO_EXP, 7.5), "m8": (q8, LO_EXP8, 448.0)}
+
+    class T:  # an activation tensor: the producer's fp32 result in ORIGINAL units + how its readers see what the device stores
+        def __init__(self, v, oe, s6=S_ACT, s8=None):
+            self.oe = torch.from_numpy(np.asarray(oe, dtype=np.float64)).view(1, -1, 1, 1, 1)      # stored = v * 2^oe
+            self.r = v * torch.exp2(self.oe)
+            self.hi = f16(self.r)
+            self.s = {"m6": s6, "m8": s8_act if s8 is None else s8}
+
+        def lo(self, fmt):                       # the stored residual as a reader of format fmt reconstructs it
+            if fmt == "x3":
+                return f16(self.r - self.hi)
+            q, le, _ = QF[fmt]
+            k = 2.0 ** (le + self.s[fmt])
+            return q((self.r - self.hi) * k) / k
+
+        def hi_q(self, fmt):                     # the code of hi that multiplies the weights' lo parts
+            q, _, _ = QF[fmt]
+            k = 2.0 ** self.s[fmt]
+            return q(self.hi * k) / k
+
+        def v(self, fmt):                        # value in original units
+            return (self.hi + self.lo(fmt)) / torch.exp2(self.oe)
+
+    def block_exp(amax, vmax):
+        am = amax.numpy()
+        E = _ilogb(am / vmax)
+        E = E + (np.ldexp(am, -E) > vmax)
+        E[am == 0] = 0
+        return torch.from_numpy(E.astype(np.float64))
+
+    def block_q(wh, wl, kind, fmt):
+        """wh, wl*2^LO: (O, Cp, T) renormalised weights, Cp = cin padded to 8. -> their block-scaled low-precision values."""
+        q, _, vmax = QF[fmt]
         O, Cp, Tn = wh.shape
         G = Cp // 8
         a, b = wh.reshape(O, G, 8, Tn), wl.reshape(O, G, 8, Tn)
@@ -88,9 +132,9 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
                 return torch.cat([z, torch.zeros(O, Up - U, 8, dtype=td)], dim=1).reshape(O, Up // 2, 2, 8)
             a, b = stream(a), stream(b)
             amax = torch.maximum(a.abs().amax(dim=(2, 3)), b.abs().amax(dim=(2, 3)))                   # (O, Up/2)
-            E = block_exp(amax).view(O, Up // 2, 1, 1)
+            E = block_exp(amax, vmax).view(O, Up // 2, 1, 1)
             back = lambda z: z.reshape(O, Up, 8)[:, :U].reshape(O, G, Tn, 8).permute(0, 1, 3, 2).reshape(O, Cp, Tn)
-            return back(q6(a / 2.0 ** E) * 2.0 ** E), back(q6(b / 2.0 ** E) * 2.0 ** E)
+            return back(q(a / 2.0 ** E) * 2.0 ** E), back(q(b / 2.0 ** E) * 2.0 ** E)
         # 1x1x1: slabs of up to 5 channel groups (tile_for), blocks = consecutive group pairs inside a slab
         aq, bq = torch.zeros_like(a), torch.zeros_like(b)
         g0 = 0
@@ -99,20 +143,13 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
             for j in range(0, n, 2):
                 sl = slice(g0 + j, min(g0 + j + 2, g0 + n))
                 amax = torch.maximum(a[:, sl].abs().amax(dim=(1, 2, 3)), b[:, sl].abs().amax(dim=(1, 2, 3)))
-                E = block_exp(amax).view(O, 1, 1, 1)
-                aq[:, sl], bq[:, sl] = q6(a[:, sl] / 2.0 ** E) * 2.0 ** E, q6(b[:, sl] / 2.0 ** E) * 2.0 ** E
+                E = block_exp(amax, vmax).view(O, 1, 1, 1)
+                aq[:, sl], bq[:, sl] = q(a[:, sl] / 2.0 ** E) * 2.0 ** E, q(b[:, sl] / 2.0 ** E) * 2.0 ** E
             g0 += n
         return aq.reshape(O, Cp, Tn), bq.reshape(O, Cp, Tn)
 
-    def block_exp(amax):
-        am = amax.numpy()
-        E = _ilogb(am / 7.5)
-        E = E + (np.ldexp(am, -E) > 7.5)
-        E[am == 0] = 0
-        return torch.from_numpy(E.astype(np.float64))
-
-    def conv(x, name, kind, act, prod, store_fmt, store_s=S_ACT, keep_unrounded=False):
-        """x: T (or a raw tensor for unrounded register inputs). Returns T (stored) [, unrounded output]."""
+    def conv(x, name, kind, act, prod, s6_out=S_ACT, raw_out=False):
+        """x: T (or a raw tensor for unrounded register inputs); prod: the layer's arithmetic. Returns T [or the fp32 result in original units]."""
         p = P[name]
         W = p["W"].astype(np.float64)
         if kind in ("dil3", "dil1"):
@@ -129,10 +166,11 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
         oe_in = torch.zeros(1, C, 1, 1, 1, dtype=td) if raw else x.oe
         Wt = torch.from_numpy(np.ascontiguousarray(W)).to(td).reshape(O, C, -1)
         if prod == "x3":
-            xv = x if raw else x.v
+            xv = x if raw else x.v("x3")
             wh = f16(Wt)
             y = cv(xv, wh + f16(Wt - wh))
         else:
+            _, le, _ = QF[prod]
             # renormalised weights: W' = W * 2^-oe_in[c] * 2^row_exp[o]
             Wr = Wt / torch.exp2(oe_in.view(1, C, 1))
             row = torch.from_numpy(-_ilogb(Wr.abs().amax(dim=(1, 2)).numpy()).astype(np.float64)).view(O, 1, 1)
@@ -140,24 +178,22 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
             Cp = (C + 7) // 8 * 8
             Wr = torch.cat([Wr, torch.zeros(O, Cp - C, Wr.shape[2], dtype=td)], dim=1)
             wh = f16(Wr)
-            wh6, wl6 = block_q6(wh, (Wr - wh) * 2.0 ** LO_EXP, kind, C)
-            wl6 = wl6 / 2.0 ** LO_EXP
-            xh6 = q6(x.hi * 2.0 ** x.s) / 2.0 ** x.s                        # renormalised units
+            whq, wlq = block_q(wh, (Wr - wh) * 2.0 ** le, kind, prod)
+            wlq = wlq / 2.0 ** le
             # all three terms in renormalised units, then undo the row exponent (the input exponent is inside W')
-            y = (cv(x.hi, wh) + cv(xh6, wl6) + cv(x.lo, wh6)) / torch.exp2(row.view(1, O, 1, 1, 1))
+            y = (cv(x.hi, wh) + cv(x.hi_q(prod), wlq) + cv(x.lo(prod), whq)) / torch.exp2(row.view(1, O, 1, 1, 1))
         scale = (p["gamma"].astype(np.float64) * p["inv_std"].astype(np.float64)).astype(np.float32)
         shift = (p["beta"].astype(np.float64) - p["mean"].astype(np.float64) * scale.astype(np.float64)).astype(np.float32)
         y = y.to(torch.float32) * torch.from_numpy(scale).view(1, -1, 1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1, 1)
         y = (torch.relu(y) if act == "relu" else torch.sigmoid(y)).to(td)
+        if raw_out:
+            return y
         oe = np.zeros(O)
         if act == "relu":
             m = np.maximum(np.abs(p["gamma"].astype(np.float64)), np.abs(p["beta"].astype(np.float64)))
             oe = np.clip(-_ilogb(m), -60, 60).astype(np.float64)
             oe[~(m > 0)] = 0
-        if store_fmt is None:
-            return y
-        out = T(y, oe, store_fmt, store_s)
-        return (out, y, oe) if keep_unrounded else out
+        return T(y, oe, (s6_of or {}).get(name, s6_out))       # s6_of: what-if premultipliers of a layer's OUTPUT tensor (fp6 readers)
 
     def up(x, name, f):
         k = P[name]["W"].shape[2]
@@ -167,31 +203,34 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3"):
         z[:, :, ::f, ::f, ::f] = x
         return F.conv3d(z.reshape(B * C, 1, *z.shape[2:]), Wk, padding=k // 2).reshape(B, C, *z.shape[2:])
 
-    A = "m6" if full else "x3"          # arithmetic / storage of the layers upstream of the concat buffer
-    x = T(torch.from_numpy(np.ascontiguousarray(X)).to(td), np.zeros(X.shape[1]), A, S_X0)
-    c11 = conv(x, "conv1_1", "conv3", "relu", A, A)
-    c12 = conv(c11, "conv1_2", "conv3", "relu", A, A)
-    c13, y13, oe13 = conv(c12, "conv1_3", "conv3", "relu", A, A, keep_unrounded=True)
-    # conv1_3 / conv2_3: side conv and pool run on the unrounded registers; the pooled tensor is stored in the layer's own format
-    s1 = conv(y13, "side_op1", "conv1", "sigmoid", "x3", None)
-    p1 = T(F.max_pool3d(y13, 2, 2), oe13, A, S_ACT)
-    c21 = conv(p1, "conv2_1", "conv3", "relu", A, A)
-    c22 = conv(c21, "conv2_2", "conv3", "relu", A, A)
-    c23, y23, oe23 = conv(c22, "conv2_3", "conv3", "relu", A, A, keep_unrounded=True)
-    s2 = T(conv(y23, "side_op2", "conv1", "sigmoid", "x3", None), np.zeros(16), A, S_ACT)
-    p2 = T(F.max_pool3d(y23, 2, 2), oe23, A, S_ACT)
-    c31 = conv(p2, "conv3_1", "conv3", "relu", A, A)
-    c32 = conv(c31, "conv3_2", "conv3", "relu", A, A)
-    c33 = conv(c32, "conv3_3", "conv3", "relu", A, A)
-    s3 = conv(c33, "side_op3", "conv1", "sigmoid", A, A)
-    c41 = conv(c33, "conv4_1", "dil3", "relu", A, A)
-    c42 = conv(c41, "conv4_2", "dil3", "relu", A, A)
-    c43 = conv(c42, "conv4_3", "dil3", "relu", A, A)
-    s4 = conv(c43, "side_op4", "dil1", "sigmoid", A, A)
-    cat_v = torch.cat([s1, up(s2.v, "side_op2_deconv", 2), up(s3.v, "side_op3_deconv", 4), up(s4.v, "side_op4_deconv", 4)], dim=1)
-    cat = T(cat_v, np.zeros(64), "m6", S_CAT)
-    ma = conv(cat, "merge_conv_a", "conv3", "relu", "m6", "m6", S_ACT)
-    mb = conv(ma, "merge_conv_b", "conv3", "relu", "m6", None)                    # stays in fp32 registers
+    A = "m6" if full else "x3"          # arithmetic / storage of the 1x1x1 layers and side maps upstream of the concat buffer
+    f = (lambda name: "m6") if full else (lambda name: fmt_of[name])
+    x = T(torch.from_numpy(np.ascontiguousarray(X)).to(td), np.zeros(X.shape[1]), S_X0, 0)
+    c11 = conv(x, "conv1_1", "conv3", "relu", f("conv1_1"))
+    c12 = conv(c11, "conv1_2", "conv3", "relu", f("conv1_2"))
+    c13 = conv(c12, "conv1_3", "conv3", "relu", f("conv1_3"))
+    y13 = c13.r / torch.exp2(c13.oe)
+    # conv1_3 / conv2_3: side conv and pool run on the unrounded registers; the pooled tensor is stored in the format its reader asks for
+    s1 = conv(y13, "side_op1", "conv1", "sigmoid", "x3", raw_out=True)
+    p1 = T(F.max_pool3d(y13, 2, 2), c13.oe.view(-1).numpy())
+    c21 = conv(p1, "conv2_1", "conv3", "relu", f("conv2_1"))
+    c22 = conv(c21, "conv2_2", "conv3", "relu", f("conv2_2"))
+    c23 = conv(c22, "conv2_3", "conv3", "relu", f("conv2_3"))
+    y23 = c23.r / torch.exp2(c23.oe)
+    s2 = T(conv(y23, "side_op2", "conv1", "sigmoid", "x3", raw_out=True), np.zeros(16))
+    p2 = T(F.max_pool3d(y23, 2, 2), c23.oe.view(-1).numpy())
+    c31 = conv(p2, "conv3_1", "conv3", "relu", f("conv3_1"))
+    c32 = conv(c31, "conv3_2", "conv3", "relu", f("conv3_2"))
+    c33 = conv(c32, "conv3_3", "conv3", "relu", f("conv3_3"))
+    s3 = conv(c33, "side_op3", "conv1", "sigmoid", A)
+    c41 = conv(c33, "conv4_1", "dil3", "relu", f("conv4_1"))
+    c42 = conv(c41, "conv4_2", "dil3", "relu", f("conv4_2"))
+    c43 = conv(c42, "conv4_3", "dil3", "relu", f("conv4_3"))
+    s4 = conv(c43, "side_op4", "dil1", "sigmoid", A)
+    cat_v = torch.cat([s1, up(s2.v(A), "side_op2_deconv", 2), up(s3.v(A), "side_op3_deconv", 4), up(s4.v(A), "side_op4_deconv", 4)], dim=1)
+    cat = T(cat_v, np.zeros(64), S_CAT)
+    ma = conv(cat, "merge_conv_a", "conv3", "relu", f("merge_conv_a"))
+    mb = conv(ma, "merge_conv_b", "conv3", "relu", f("merge_conv_b"), raw_out=True)                    # stays in fp32 registers
     p3 = P["merge_conv3"]
     w3 = torch.from_numpy(np.ascontiguousarray(p3["W"].astype(np.float64))).to(td)
     y = F.conv3d(mb, w3)

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "sn_ray_pool", "sn_ray_pool_dev", "sn_dense2sparse", "sn_dense2sparse_dev",
     "sn_simil_load_weights", "sn_crop_patches", "sn_patch2embedding", "sn_crop_embed", "sn_embeddingpair2simil", "sn_embeddings2simil",
     "sn_project_points",
-    "sn_comm_unique_id", "sn_comm_init", "sn_allgather_f32_dev", "sn_allgather_f32_dev_overlap", "sn_comm_wait", "sn_allgatherv_bytes_dev",
+    "sn_comm_unique_id", "sn_comm_init", "sn_comm_init_deadline", "sn_comm_info", "sn_allgather_f32_dev", "sn_allgather_f32_dev_overlap", "sn_comm_wait", "sn_allgatherv_counts", "sn_allgatherv_bytes_dev",
     "sn_calibrate_dev", "sn_numeric_status",
     "sn_profile_enable", "sn_profile_count", "sn_profile_get", "sn_profile_reset",
 ]
@@ -105,11 +105,14 @@ def load():
         "sn_project_points": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
         "sn_comm_unique_id": (c_int, [ctypes.c_char_p]),
         "sn_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p]),
+        "sn_comm_init_deadline": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p, ctypes.c_double]),
+        "sn_comm_info": (c_int, [ctypes.c_char_p, c_int, P(c_int)]),
         "sn_calibrate_dev": (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p]),
         "sn_numeric_status": (c_int, [c_void_p, c_void_p, ctypes.c_char_p, c_int]),
         "sn_allgather_f32_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
         "sn_allgather_f32_dev_overlap": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
         "sn_comm_wait": (c_int, [c_void_p, c_int]),
+        "sn_allgatherv_counts": (c_int, [c_void_p, c_size_t, c_void_p]),
         "sn_allgatherv_bytes_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
         "sn_profile_enable": (c_int, [c_void_p, c_int]),
         "sn_profile_count": (c_int, [c_void_p]),

@@ -8,6 +8,59 @@ from . import _lib, weights as _weights
 MEAN_CVC_RGBRGB = np.asarray([123.68, 116.779, 103.939, 123.68, 116.779, 103.939]).astype(np.float32)  # params.py:129
 
 
+def allgatherv_two_step(n_local, counts_fn, payload_fn):
+    """The rank-uniform protocol of `Context.allgatherv_bytes`, separated from the C calls so that the multi-rank CPU tests can drive it over gloo:
+    `counts_fn(n_local)` -> the per-rank byte counts (one collective), `payload_fn(n_local, total)` -> (counts, the `total` gathered bytes) (the
+    collectives of sn_allgatherv_bytes_dev). Every rank calls the two in this order exactly once: the total is the same number everywhere, so the
+    sizing of the destination can never send one rank back into a collective its peers have left."""
+    counts = counts_fn(n_local)
+    total = int(sum(counts))
+    counts2, out = payload_fn(n_local, total)
+    if list(counts2) != list(counts):
+        raise _lib.SurfaceNetHipError("allgatherv: the ranks' counts changed between the two steps (%r -> %r): mismatched collectives" % (counts, counts2))
+    ends = np.cumsum(counts)
+    return [out[e - c: e] for c, e in zip(counts, ends)]
+
+
+class NumericsGuard(object):
+    """The numerics safety net of the default mode for ONE caller (a drop-in callable, a cube loop, a scene): the two merge layers read their inputs
+    as fp16 + 6-bit codes under per-tensor premultipliers that are static - sized from the BatchNorm parameters a trained net obeys. A net that does
+    not obey them saturates codes (each such value loses its own correction term); the library raises a WARNING word for that (`numeric_status`) and
+    can derive the premultipliers from data instead (`calibrate`). `check()` - called by the caller right after its first batch, then once per
+    scene / per call - reads the word; on the first saturation report it calibrates on the batch that was just run, emits ONE `RuntimeWarning`
+    naming the layers and the exponents chosen, and returns the calibration report: the caller then REDOES that batch (nets/SurfaceNet.py:385-402
+    is where the only weights that will ever matter are loaded; main_reconstruct.py:145-146 is the call this protects). Afterwards the word is still
+    read (and cleared) but a calibrated context reports nothing more: the calibration itself tolerates `max_sat_fraction` of saturated values."""
+
+    def __init__(self, ctx, enabled=True, max_sat_fraction=1e-3):
+        self.ctx, self.enabled, self.max_sat_fraction = ctx, bool(enabled), float(max_sat_fraction)
+        self.calibrated, self.report, self.checks = False, None, 0
+
+    def check(self, where="forward"):
+        if not self.enabled:
+            return None
+        self.checks += 1
+        names = self.ctx.numeric_status()
+        if not names or self.calibrated:
+            return None
+        import warnings
+        self.calibrated = True                   # one attempt, one warning per caller
+        if self.ctx.precision != "f16x3":
+            warnings.warn("surfacenet_amd (%s): stored activations of %s exceed the range of their 6-bit code planes; precision mode %r has no "
+                          "data-driven premultipliers - accuracy degrades towards plain fp16 for those values" % (where, ", ".join(names), self.ctx.precision),
+                          RuntimeWarning, stacklevel=3)
+            return None
+        cal = self.ctx.calibrate(0, self.max_sat_fraction)
+        self.report = cal
+        warnings.warn("surfacenet_amd (%s): stored activations of %s exceeded the range of their 6-bit code planes (%.2f %% of merge_conv_a's non-zero "
+                      "outputs, %.2f %% of the concat buffer; the network's BatchNorm statistics under-estimate their spread). Premultipliers "
+                      "recalibrated on this batch: s_act %d -> %d, s_cat %d -> %d (saturated fraction now %.3f %% / %.3f %%); the batch is recomputed. "
+                      "Pass auto_calibrate=False to keep the static exponents."
+                      % (where, ", ".join(names), 100 * cal["sat_act_before"], 100 * cal["sat_cat_before"], cal["s_act_before"], cal["s_act"],
+                         cal["s_cat_before"], cal["s_cat"], 100 * cal["sat_act"], 100 * cal["sat_cat"]), RuntimeWarning, stacklevel=3)
+        return cal
+
+
 class Context(object):
     PRECISIONS = {"f16": 0, "f16x3": 1, "f16m8": 2, "f16x3p": 3}      # f16x3p: f16x3 without the MX tail (see surfacenet_hip.h)
 
@@ -328,9 +381,9 @@ class Context(object):
                                                  votes_ws_dev, offsets_dev, ijk_dev, pred16_dev, rgb_out_dev, votes_out_dev))
 
     # ---- numerics of the 6-bit code planes (default mode) ---------------------------------------------------
-    def calibrate(self, n_samples, max_sat_fraction=1e-3):
+    def calibrate(self, n_samples=0, max_sat_fraction=1e-3):
         """Data-driven premultipliers of the two code planes (sn_calibrate_dev): looks at the activations the LAST forward call left in the
-        workspace (`n_samples` of them - run `forward` / `cvc_forward` on a representative batch first) and sets each plane's exponent to the
+        workspace (`n_samples` of them, 0 = all that call ran - run `forward` / `cvc_forward` on a representative batch first) and sets each plane's exponent to the
         largest one that saturates at most `max_sat_fraction` of the values. Returns a dict (exponents and saturated fractions before / after,
         largest magnitudes). The setting holds until the next load_param_values / precision change."""
         cal = _lib.Calibration()
@@ -353,9 +406,19 @@ class Context(object):
         _lib.check(_lib.load().sn_comm_unique_id(buf))
         return buf.raw
 
-    def comm_init(self, world, rank, unique_id):
-        _lib.check(self._lib.sn_comm_init(self._h, int(world), int(rank), ctypes.c_char_p(bytes(unique_id))))
+    def comm_init(self, world, rank, unique_id, timeout_s=None):
+        """Joins the RCCL communicator (collective: every rank calls it with rank 0's unique id). timeout_s: bound on the wait for the other ranks
+        (sn_comm_init_deadline: SurfaceNetHipError when it expires, the context stays usable without a communicator); None = wait for ever."""
+        self.comm_world = self.comm_rank = 0
+        _lib.check(self._lib.sn_comm_init_deadline(self._h, int(world), int(rank), ctypes.c_char_p(bytes(unique_id)), float(timeout_s or 0.0)))
         self.comm_world, self.comm_rank = int(world), int(rank)
+
+    @staticmethod
+    def comm_info():
+        """-> (file the RCCL entry points are bound to [+ whether the process had it mapped already], ncclGetVersion code)."""
+        buf, ver = ctypes.create_string_buffer(1024), ctypes.c_int(0)
+        _lib.check(_lib.load().sn_comm_info(buf, 1024, ctypes.byref(ver)))
+        return buf.value.decode("utf-8", "replace"), int(ver.value)
 
     def allgather_f32_dev(self, local_dev, n_local, global_dev):
         _lib.check(self._lib.sn_allgather_f32_dev(self._h, local_dev, int(n_local), global_dev))
@@ -369,36 +432,37 @@ class Context(object):
         _lib.check(self._lib.sn_comm_wait(self._h, int(slot)))
 
     def allgatherv_bytes(self, blob):
-        """Variable-length all-gather of one byte string per rank through the library's RCCL binding (sn_allgatherv_bytes_dev): `blob` (np.uint8, any
-        length incl. 0) -> list of `world` np.uint8 arrays in rank order. The payloads travel device to device over xGMI; only this rank's blob goes
-        up and the gathered bytes come down."""
+        """Variable-length all-gather of one byte string per rank through the library's RCCL binding: `blob` (np.uint8, any length incl. 0) -> list
+        of `world` np.uint8 arrays in rank order. The payloads travel device to device over xGMI; only this rank's blob goes up and the gathered
+        bytes come down. Collective sequence, identical on every rank whatever the blob sizes are (`allgatherv_two_step`): the counts
+        (sn_allgatherv_counts), then counts + payloads into a buffer sized from them (sn_allgatherv_bytes_dev) - no rank ever retries on its own."""
         world = getattr(self, "comm_world", 0)
         if not world:
             raise _lib.SurfaceNetHipError("allgatherv_bytes: comm_init has not been called on this context")
         blob = np.ascontiguousarray(np.asarray(blob, dtype=np.uint8).reshape(-1))
         d_local = self.upload(blob) if blob.size else None
-        counts = (ctypes.c_ulonglong * world)()
-        cap = max(64, 2 * world * max(int(blob.size), 1))
-        try:
-            while True:
-                d_all = self.dev_alloc(cap)
-                rc = self._lib.sn_allgatherv_bytes_dev(self._h, d_local, int(blob.size), d_all, cap, counts)
-                total = int(sum(counts))
-                if rc != 0 and total > cap:          # the ranks' contributions were larger than guessed: the counts are filled in, retry once
-                    self.dev_free(d_all)
-                    cap = total
-                    continue
-                _lib.check(rc)
+
+        def counts_fn(n_local):
+            counts = (ctypes.c_ulonglong * world)()
+            _lib.check(self._lib.sn_allgatherv_counts(self._h, int(n_local), counts))
+            return [int(c) for c in counts]
+
+        def payload_fn(n_local, total):
+            counts = (ctypes.c_ulonglong * world)()
+            d_all = self.dev_alloc(max(total, 16))
+            try:
+                _lib.check(self._lib.sn_allgatherv_bytes_dev(self._h, d_local, int(n_local), d_all, int(total), counts))
                 out = np.empty((total,), dtype=np.uint8)
                 if total:
                     self.d2h(out, d_all)
+            finally:
                 self.dev_free(d_all)
-                break
+            return [int(c) for c in counts], out
+        try:
+            return allgatherv_two_step(int(blob.size), counts_fn, payload_fn)
         finally:
             if d_local is not None:
                 self.dev_free(d_local)
-        ends = np.cumsum([int(c) for c in counts])
-        return [out[e - int(c): e] for c, e in zip(counts, ends)]
 
     # ---- measurement --------------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -221,6 +221,9 @@ __device__ __forceinline__ void sn_track_acc(f32x2_t &c, const f32x4 &a)
 // (round 4: the stored-value tracker is a packed MAX, same cost - every store epilogue stores non-negative values (ReLU / sigmoid / pooled ReLU), so the
 // largest stored half is +inf exactly when a value left the fp16 range, and the same register also says whether a value exceeded the range of the
 // 6-bit code plane its tensor carries: the saturation warning of ConvArgs::mx_sat_bits)
+// (v_pk_max_f16 drops a quiet-NaN operand: a stored NaN half whose ACCUMULATOR was finite would pass. That takes a NaN folded scale / shift - e.g.
+// sigmoid(NaN) in a 1x1x1 side convolution - and pack_conv_host rejects every non-finite folded constant at load time (SN_ERR_ARG naming the layer and
+// channel; tests/test_gpu_numerics.py::test_non_finite_batchnorm_constants_are_rejected_at_load), so no NaN can enter behind sn_track_acc. ADVICE r4.)
 __device__ __forceinline__ void sn_track_h2(unsigned &c, unsigned h2) { asm volatile("v_pk_max_f16 %0, %1, %0" : "+v"(c) : "v"(h2)); }
 __device__ __forceinline__ unsigned sn_tracked_max_bits(unsigned h) { const unsigned lo = h & 0x7fffu, hi = (h >> 16) & 0x7fffu; return lo > hi ? lo : hi; }   // fp16 bits of the largest stored value
 __device__ __forceinline__ bool sn_tracked_bad(const f32x2_t &c, unsigned h) { return !(c.x == 0.f && c.y == 0.f) || sn_tracked_max_bits(h) >= 0x7c00u; }

@@ -459,7 +459,10 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
 
 static int run_net(sn_ctx *c, int S, float *unf)
 {
-    return c->split == 2 ? run_net_t<2>(c, S, unf) : (c->split == 1 ? run_net_t<1>(c, S, unf) : run_net_t<0>(c, S, unf));
+    c->last_run_samples = 0;
+    const int rc = c->split == 2 ? run_net_t<2>(c, S, unf) : (c->split == 1 ? run_net_t<1>(c, S, unf) : run_net_t<0>(c, S, unf));
+    if (rc == SN_OK) c->last_run_samples = S;      // (what sn_calibrate_dev may scan)
+    return rc;
 }
 
 static int launch_fuse(sn_ctx *c, const float *unf, const float *w_dev, float *fused, int n, int n_vp)
@@ -607,6 +610,7 @@ int sn_set_precision(sn_ctx *c, int mode)
     c->mode = mode;
     c->split = mode == SN_PRECISION_F16X3_PURE ? 1 : mode;
     c->tail_m8 = mode == SN_PRECISION_F16X3 ? 2 : 0;
+    c->last_run_samples = 0;
     if (mode == SN_PRECISION_F16X3 && sn_ab_switch("SN_M8_TAIL")) c->tail_m8 = std::max(0, std::min(2, atoi(sn_ab_switch("SN_M8_TAIL"))));   // A/B measurements only
     reset_mx_exponents(c);
     return SN_OK;
@@ -674,9 +678,17 @@ int sn_numeric_status(sn_ctx *c, unsigned *saturated_bits, char *names, int name
 int sn_calibrate_dev(sn_ctx *c, int n_samples, double max_sat_fraction, sn_calibration *out)
 {
     if (!c || !out) return fail(SN_ERR_ARG, "null argument");
-    if (!(c->split == 2 || (c->split == 1 && c->tail_m8 >= 2)) || SN_MX_FMT == 0)
-        return fail(SN_ERR_STATE, "sn_calibrate_dev: this precision mode stores no 6-bit code planes");
-    if (!c->cat || !c->ma || n_samples < 1 || n_samples > c->max_samples) return fail(SN_ERR_ARG, "sn_calibrate_dev: n_samples must be 1..max_samples, after a forward call");
+    // The default (hybrid) mode only: there the two exponents belong to exactly the two tensors scanned below - the concat buffer and merge_conv_a's
+    // output. In the all-MX mode (SN_PRECISION_F16M8) mx_act_e8 is also the exponent of every tensor upstream, which the pooling / upsampling
+    // kernels decode with the compile-time default: calibrating it from merge_conv_a's output alone would desynchronise them.
+    if (!(c->split == 1 && c->tail_m8 >= 2) || SN_MX_FMT == 0)
+        return fail(SN_ERR_STATE, "sn_calibrate_dev: only the default precision mode (SN_PRECISION_F16X3) carries calibratable 6-bit code planes");
+    if (!c->cat || !c->ma || n_samples > c->max_samples) return fail(SN_ERR_ARG, "sn_calibrate_dev: n_samples must be 1..max_samples (or <= 0: all samples of the last forward call)");
+    if (c->last_run_samples <= 0)
+        return fail(SN_ERR_STATE, "sn_calibrate_dev: no forward call has run since the weights / the precision mode were set - run a representative batch first");
+    if (n_samples <= 0) n_samples = c->last_run_samples;
+    if (n_samples > c->last_run_samples)
+        return fail(SN_ERR_STATE, "sn_calibrate_dev: the last forward call ran %d samples, %d were asked for (the rest of the workspace holds older data)", c->last_run_samples, n_samples);
     if (!(max_sat_fraction >= 0.0 && max_sat_fraction < 1.0)) return fail(SN_ERR_ARG, "sn_calibrate_dev: max_sat_fraction must be in [0, 1)");
     HIPCHK(hipSetDevice(c->device));
     const long long vox = (long long)c->s * c->s * c->s;
@@ -698,7 +710,11 @@ int sn_calibrate_dev(sn_ctx *c, int n_samples, double max_sat_fraction, sn_calib
     double sat_new[2], sat_old[2];
     const int s_old[2] = {127 - c->mx_act_e8, 127 - c->mx_cat_e8};
     for (int t = 0; t < 2; ++t) {
-        const double nz = (double)std::max<unsigned long long>(h[t][kMxScanBins], 1);
+        if (h[t][kMxScanBins] == 0) {      // an all-zero tensor says nothing about its range: the exponent stays
+            s_new[t] = s_old[t]; sat_new[t] = sat_old[t] = 0.0;
+            continue;
+        }
+        const double nz = (double)h[t][kMxScanBins];
         auto frac = [&](int s) { const int j = std::max(0, std::min(kMxScanBins - 1, s + kMxScanBins / 2)); return (double)h[t][j] / nz; };
         int s = -kMxScanBins / 2;
         for (int cand = kMxScanBins / 2; cand >= -kMxScanBins / 2; --cand)
@@ -731,6 +747,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
     for (auto &kv : c->conv) { dev_free_owned(c, kv.second.wpack); dev_free_owned(c, kv.second.scale); dev_free_owned(c, kv.second.shift); dev_free_owned(c, kv.second.side_frag); }
     c->conv.clear();
     c->have_weights = false;
+    c->last_run_samples = 0;
 
     // per-channel output exponents of the ReLU layers (see pack_conv): the stored activation is y * 2^e with e chosen from the
     // layer's own BatchNorm so that its typical magnitude (|gamma| + |beta|: z ~ N(beta, gamma^2) under true statistics) is O(1)
@@ -792,6 +809,9 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
             HIPCHK(hipMemcpy(c->w3, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
             c->scale3 = gamma[0] * inv_std[0];
             c->shift3 = beta[0] - mean[0] * c->scale3;
+            bool fin = std::isfinite(c->scale3) && std::isfinite(c->shift3);
+            for (int ci = 0; ci < sp.cin; ++ci) fin = fin && std::isfinite(w3[ci]);
+            if (!fin) return fail(SN_ERR_ARG, "merge_conv3: non-finite weight or folded BatchNorm scale / shift");
             continue;
         }
         PackedConv L;
@@ -1156,12 +1176,20 @@ struct Rccl {
 };
 struct UniqueId { char b[128]; };
 Rccl g_rccl;
+std::string g_rccl_file;                          // the shared object the entry points were bound from (dladdr)
 int rccl_load()
 {
     if (g_rccl.h) return SN_OK;
+    // A process that already carries an RCCL (torch.distributed's, say) must not get a second copy with its own topology state and its own view of the
+    // devices: an already-mapped library is taken first (RTLD_NOLOAD finds it by soname whatever directory it came from); only then is one loaded.
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    bool was_mapped = true;
+    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+    if (!h) {
+        was_mapped = false;
+        for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    }
     if (!h) return fail(SN_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
     g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void **, int, const char (*)[128], int))dlsym(h, "ncclCommInitRank");
@@ -1178,6 +1206,9 @@ int rccl_load()
         dlclose(h);
         return fail(SN_ERR_COMM, "librccl reports version code %d: this library binds the NCCL 2.x ABI only", ver);
     }
+    Dl_info info;
+    g_rccl_file = (dladdr((void *)g_rccl.AllGather, &info) && info.dli_fname) ? info.dli_fname : "?";
+    g_rccl_file += was_mapped ? " (already mapped by the host process)" : " (loaded by libsurfacenet_hip)";
     g_rccl.version = ver;
     g_rccl.h = h;
     return SN_OK;
@@ -1203,21 +1234,71 @@ int sn_comm_unique_id(char *id128)
     return SN_OK;
 }
 
-int sn_comm_init(sn_ctx *c, int world, int rank, const char *id128)
+// Which RCCL the communicator entry points are bound to: the file (and whether the host process had it mapped already) and its ncclGetVersion code.
+// Loads the library if nothing has yet. A process with TWO RCCL copies (torch's and this one's) shows up here, not as a hang at the first collective.
+int sn_comm_info(char *file, int file_cap, int *version_code)
+{
+    int rc = rccl_load();
+    if (rc != SN_OK) return rc;
+    if (file && file_cap > 0) snprintf(file, (size_t)file_cap, "%s", g_rccl_file.c_str());
+    if (version_code) *version_code = g_rccl.version;
+    return SN_OK;
+}
+
+// ncclCommInitRank blocks until every rank of the group has called it. sn_comm_init_deadline bounds that wait: the call runs in a helper thread
+// and the caller waits at most timeout_s for it; on a timeout the context stays without a communicator (SN_ERR_COMM), the helper thread - still
+// inside RCCL, where nothing can interrupt it - is abandoned together with the few bytes of state it owns, and the context remains usable for
+// everything but the exchange. sn_comm_init = the same without a deadline (the caller vouches that all ranks arrive).
+struct CommInitJob {
+    std::mutex m; std::condition_variable cv;
+    bool done = false; int err = 0; void *comm = nullptr; bool abandoned = false;
+    int device = 0, world = 0, rank = 0; UniqueId uid;
+};
+
+int sn_comm_init_deadline(sn_ctx *c, int world, int rank, const char *id128, double timeout_s)
 {
     if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SN_ERR_ARG, "bad argument");
     int rc = rccl_load();
     if (rc != SN_OK) return rc;
     HIPCHK(hipSetDevice(c->device));
     if (c->rccl_comm) { g_rccl.CommDestroy(c->rccl_comm); c->rccl_comm = nullptr; }
-    UniqueId uid;
-    memcpy(uid.b, id128, 128);
+    c->comm_world = 0; c->comm_rank = 0;
     typedef int (*init_fn)(void **, int, UniqueId, int);                   // ncclUniqueId is passed BY VALUE
-    const int e = ((init_fn)g_rccl.CommInitRank)(&c->rccl_comm, world, uid, rank);
-    if (e != 0) { c->rccl_comm = nullptr; return fail(SN_ERR_COMM, "ncclCommInitRank: %s", rccl_err(e)); }
+    if (!(timeout_s > 0.0)) {
+        UniqueId uid;
+        memcpy(uid.b, id128, 128);
+        const int e = ((init_fn)g_rccl.CommInitRank)(&c->rccl_comm, world, uid, rank);
+        if (e != 0) { c->rccl_comm = nullptr; return fail(SN_ERR_COMM, "ncclCommInitRank: %s", rccl_err(e)); }
+        c->comm_world = world; c->comm_rank = rank;
+        return SN_OK;
+    }
+    auto job = std::make_shared<CommInitJob>();
+    job->device = c->device; job->world = world; job->rank = rank;
+    memcpy(job->uid.b, id128, 128);
+    std::thread([job]() {
+        void *comm = nullptr;
+        int e = (hipSetDevice(job->device) == hipSuccess) ? ((init_fn)g_rccl.CommInitRank)(&comm, job->world, job->uid, job->rank) : -1;
+        std::unique_lock<std::mutex> lk(job->m);
+        if (job->abandoned) {                                   // the caller gave up on us: nobody will ever use this communicator
+            if (e == 0 && comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+            return;
+        }
+        job->err = e; job->comm = comm; job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->m);
+    if (!job->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return job->done; })) {
+        job->abandoned = true;
+        return fail(SN_ERR_COMM, "ncclCommInitRank (rank %d of %d) did not return within %.0f s: not every rank joined, or the ranks' RCCL copies cannot reach each other "
+                                 "(sn_comm_info names the library bound here)", rank, world, timeout_s);
+    }
+    if (job->err != 0) return fail(SN_ERR_COMM, "ncclCommInitRank: %s", job->err == -1 ? "hipSetDevice failed in the helper thread" : rccl_err(job->err));
+    c->rccl_comm = job->comm;
     c->comm_world = world; c->comm_rank = rank;
     return SN_OK;
 }
+
+int sn_comm_init(sn_ctx *c, int world, int rank, const char *id128) { return sn_comm_init_deadline(c, world, rank, id128, 0.0); }
 
 // Every rank contributes n_local floats (device); global_dev receives world*n_local floats in rank order. Asynchronous
 // on the context's stream (use sn_synchronize).
@@ -1265,44 +1346,71 @@ int sn_comm_wait(sn_ctx *c, int slot)
 // Variable-length all-gather of bytes ("gather sparse voxels ... counts then all-gather-v"): every rank contributes n_local bytes
 // (device memory; n_local may be 0 and may differ from rank to rank), global_dev receives the contributions back to back in rank order, counts[r]
 // (host, `world` entries) their sizes. Two RCCL all-gathers on the context's stream - the 8-byte counts, then the payloads padded to the largest -
-// and one device-to-device copy per rank that closes the gaps. Synchronous (the host needs the counts to size the second step); returns
-// SN_ERR_ARG when global_cap bytes cannot hold the total, with counts[] filled so that the caller can retry with a larger buffer.
+// and one device-to-device copy per rank that closes the gaps. Synchronous (the host needs the counts to size the second step).
+// EVERY rank issues the SAME sequence of collectives whatever its own arguments are: the only rank-local failure, a destination that cannot hold the
+// total, is reported AFTER the payload all-gather has run (SN_ERR_ARG with counts[] filled in), so a rank that fails never leaves its peers inside a
+// collective it does not take part in (the first version returned between the two all-gathers, and a caller that retried on its own then
+// issued a counts all-gather against its peers' payload all-gather). sn_allgatherv_counts is the sizing query: the counts all-gather alone.
+static int comm_stage_need(sn_ctx *c, size_t bytes)
+{
+    if (bytes <= c->comm_stage_cap) return SN_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->comm_stage) { dev_free_owned(c, c->comm_stage); c->comm_stage = nullptr; c->comm_stage_cap = 0; }
+    int rc = dev_alloc(c, &c->comm_stage, bytes);
+    if (rc != SN_OK) return rc;
+    c->comm_stage_cap = bytes;
+    return SN_OK;
+}
+static int comm_gather_counts(sn_ctx *c, size_t n_local, unsigned long long *counts)
+{
+    const int W = c->comm_world;
+    int rc = comm_stage_need(c, (size_t)(W + 1) * 8);
+    if (rc != SN_OK) return rc;
+    const unsigned long long mine = n_local;
+    HIPCHK(hipMemcpyAsync(c->comm_stage + (size_t)W * 8, &mine, 8, hipMemcpyHostToDevice, c->stream));
+    const int e = g_rccl.AllGather(c->comm_stage + (size_t)W * 8, c->comm_stage, 8, /*ncclUint8*/ 1, c->rccl_comm, c->stream);
+    if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather (counts): %s", rccl_err(e));
+    HIPCHK(hipMemcpyAsync(counts, c->comm_stage, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SN_OK;
+}
+
+int sn_allgatherv_counts(sn_ctx *c, size_t n_local, unsigned long long *counts)
+{
+    if (!c || !counts) return fail(SN_ERR_ARG, "null argument");
+    if (!c->rccl_comm) return fail(SN_ERR_STATE, "sn_comm_init has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    return comm_gather_counts(c, n_local, counts);
+}
+
 int sn_allgatherv_bytes_dev(sn_ctx *c, const void *local_dev, size_t n_local, void *global_dev, size_t global_cap, unsigned long long *counts)
 {
     if (!c || !counts || (n_local && !local_dev)) return fail(SN_ERR_ARG, "null argument");
     if (!c->rccl_comm) return fail(SN_ERR_STATE, "sn_comm_init has not been called");
     HIPCHK(hipSetDevice(c->device));
     const int W = c->comm_world;
-    auto need_stage = [&](size_t bytes) -> int {
-        if (bytes <= c->comm_stage_cap) return SN_OK;
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->comm_stage) { dev_free_owned(c, c->comm_stage); c->comm_stage = nullptr; c->comm_stage_cap = 0; }
-        int rc = dev_alloc(c, &c->comm_stage, bytes);
-        if (rc != SN_OK) return rc;
-        c->comm_stage_cap = bytes;
-        return SN_OK;
-    };
-    int rc = need_stage((size_t)(W + 1) * 8);
+    int rc = comm_gather_counts(c, n_local, counts);
     if (rc != SN_OK) return rc;
-    const unsigned long long mine = n_local;
-    HIPCHK(hipMemcpyAsync(c->comm_stage + (size_t)W * 8, &mine, 8, hipMemcpyHostToDevice, c->stream));
-    int e = g_rccl.AllGather(c->comm_stage + (size_t)W * 8, c->comm_stage, 8, /*ncclUint8*/ 1, c->rccl_comm, c->stream);
-    if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather (counts): %s", rccl_err(e));
-    HIPCHK(hipMemcpyAsync(counts, c->comm_stage, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     unsigned long long total = 0, cap = 0;
     for (int r = 0; r < W; ++r) { total += counts[r]; cap = std::max(cap, counts[r]); }
-    if (total > global_cap) return fail(SN_ERR_ARG, "sn_allgatherv_bytes_dev: %llu bytes gathered, the destination holds %zu", total, global_cap);
-    if (total == 0) return SN_OK;
-    if (!global_dev) return fail(SN_ERR_ARG, "null destination");
+    if (total == 0) return SN_OK;                                  // (the same on every rank: nobody enters the payload step)
     cap = (cap + 15) & ~15ull;
-    rc = need_stage((size_t)(W + 1) * cap);                      // [W padded payloads | this rank's padded payload]
+    rc = comm_stage_need(c, (size_t)(W + 1) * cap);              // [W padded payloads | this rank's padded payload]
     if (rc != SN_OK) return rc;
     unsigned char *mine_pad = c->comm_stage + (size_t)W * cap;
     if (n_local) HIPCHK(hipMemcpyAsync(mine_pad, local_dev, n_local, hipMemcpyDeviceToDevice, c->stream));
-    ProfScope ps(c, "rccl_allgatherv", 0, (double)cap * W);
-    e = g_rccl.AllGather(mine_pad, c->comm_stage, cap, /*ncclUint8*/ 1, c->rccl_comm, c->stream);
+    int e;
+    {
+        ProfScope ps(c, "rccl_allgatherv", 0, (double)cap * W);
+        e = g_rccl.AllGather(mine_pad, c->comm_stage, cap, /*ncclUint8*/ 1, c->rccl_comm, c->stream);
+    }
     if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather (payload): %s", rccl_err(e));
+    // rank-local checks only from here on: every collective of the call has been issued
+    if (total > global_cap || !global_dev) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return fail(SN_ERR_ARG, "sn_allgatherv_bytes_dev: %llu bytes gathered, the destination holds %zu (size it with sn_allgatherv_counts)", total,
+                    global_dev ? global_cap : (size_t)0);
+    }
     size_t off = 0;
     for (int r = 0; r < W; ++r) {
         if (counts[r]) HIPCHK(hipMemcpyAsync(static_cast<unsigned char *>(global_dev) + off, c->comm_stage + (size_t)r * cap, counts[r], hipMemcpyDeviceToDevice, c->stream));

@@ -6,7 +6,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -100,6 +105,7 @@ struct sn_ctx {
     int tail_m8 = 2;            // f16x3: how many of the last 3x3x3 layers run their two correction terms on the MX-fp8 MFMA
                                 // (0 none = f16x3p, 1 merge_conv_b, 2 merge_conv_a + merge_conv_b); env SN_M8_TAIL overrides (A/B runs)
     bool ws_ready = false; int ws_split = -1;
+    int last_run_samples = 0;   // samples of the last network run whose activations are still in the workspace (0: none since the weights / mode changed) - sn_calibrate_dev
     std::map<std::string, PackedConv> conv;
     float *w3 = nullptr; float scale3 = 0, shift3 = 0;
     void *zero_page = nullptr; int num_cus = 256;

@@ -21,7 +21,7 @@
 """
 import numpy as np
 
-from .context import MEAN_CVC_RGBRGB
+from .context import MEAN_CVC_RGBRGB, NumericsGuard
 
 
 def gen_non0Batch_npBool(boolIndicators, batch_size):
@@ -36,18 +36,24 @@ def gen_non0Batch_npBool(boolIndicators, batch_size):
     return np.array(out)
 
 
-def hot_loop(ctx, validCubes, viewPairs4Reconstr, w_viewPairs4Reconstr, cubes_param_np, batch_size, return_cvc=True):
+def hot_loop(ctx, validCubes, viewPairs4Reconstr, w_viewPairs4Reconstr, cubes_param_np, batch_size, return_cvc=True, auto_calibrate=True):
     """main_reconstruct.py:132-150 for every batch: yields (_batch, surfacePrediction (n,1,s,s,s), unfused (n,N_vp,s,s,s),
     _CVCs2_sub + mean (n*N_vp,6,s,s,s) raw colours or None). `cubes_param_np` is the reference's structured array
-    ('xyz' f32x3, 'resol' f32, ...; utils/scene.py:7-61)."""
+    ('xyz' f32x3, 'resol' f32, ...; utils/scene.py:7-61).
+    auto_calibrate (default on): the saturation warning of the default mode's 6-bit code planes is read after every batch; the first report
+    recalibrates the premultipliers on that batch, which is recomputed, with one RuntimeWarning (context.NumericsGuard)."""
     validCubes = np.asarray(validCubes).astype(bool)
     n_vp = viewPairs4Reconstr.shape[1]
     mean = MEAN_CVC_RGBRGB[None, :, None, None, None]
+    guard = NumericsGuard(ctx, enabled=auto_calibrate)
     for _batch in gen_non0Batch_npBool(validCubes, batch_size):
         sel = _batch[validCubes]
         w = None if n_vp == 1 else np.ascontiguousarray(w_viewPairs4Reconstr[sel], dtype=np.float32)
-        fused, unfused, cvc = ctx.cvc_forward(viewPairs4Reconstr[sel], cubes_param_np["xyz"][_batch], cubes_param_np["resol"][_batch],
-                                              w, return_unfused=True, return_cvc=return_cvc)
+        args = (viewPairs4Reconstr[sel], cubes_param_np["xyz"][_batch], cubes_param_np["resol"][_batch], w)
+        fused, unfused, cvc = ctx.cvc_forward(*args, return_unfused=True, return_cvc=return_cvc)
+        if guard.check("hot_loop") is not None:
+            fused, unfused, cvc = ctx.cvc_forward(*args, return_unfused=True, return_cvc=return_cvc)      # recalibrated on this batch: redo it
+            ctx.numeric_status()
         if cvc is not None:
             cvc += mean          # main_reconstruct.py:150
         yield _batch, fused, (fused if n_vp == 1 else unfused), cvc
@@ -73,11 +79,13 @@ class SparseLoop(object):
     run(viewPairs (n,N_vp,2), xyz (n,3), resol (n,), w (n,N_vp)) returns what `sparseCubes.dense2sparse` returns for
     the batch: (nonempty_cube_indx, vxl_ijk_list, prediction_list, rgb_list, rayPooling_votes_list, xyz_new) with the
     keyword settings given at construction (defaults = the reference's call: min_prob params.__min_prob, rayPool_thresh 0,
-    centre crop on, ray pooling on)."""
+    centre crop on, ray pooling on). auto_calibrate (default on): the first batch whose stored activations exceed the range of the default mode's 6-bit
+    code planes recalibrates their premultipliers and is recomputed, with one RuntimeWarning (context.NumericsGuard)."""
 
     def __init__(self, ctx, n_vp, max_cubes=None, min_prob=0.5, rayPool_thresh=0, enable_centerCrop=True, cube_Dcenter=None,
-                 enable_rayPooling=True, mean=MEAN_CVC_RGBRGB):
+                 enable_rayPooling=True, mean=MEAN_CVC_RGBRGB, auto_calibrate=True):
         self.ctx, self.n_vp = ctx, int(n_vp)
+        self.guard = NumericsGuard(ctx, enabled=auto_calibrate)     # saturation of the 6-bit code planes: checked on the first batch, then once per call
         s = ctx.cube_D
         self.max_cubes = int(max_cubes or max(1, ctx.max_samples // self.n_vp))
         if self.max_cubes * self.n_vp > ctx.max_samples:
@@ -121,6 +129,9 @@ class SparseLoop(object):
         ctx.color_fuse_dev(n, n_vp, d["cvc"], d["unfused"], d["w"], d["rgb"], mean=self.mean)      # main_reconstruct.py:150-152
         ctx.dense2sparse_dev(n, n_vp, d["pairs"], d["xyz"], d["resol"], d["fused"], d["rgb"], d["votes"], d["offsets"], d["ijk"], d["p16"],
                              d["rgb_out"], d["votes_out"], **self.cfg)                                 # :153-160
+        if self.guard.check("SparseLoop.run") is not None:
+            ctx.numeric_status()
+            return self.run(viewPairs, xyz, resol, w)              # premultipliers recalibrated on this batch: redo it (the guard acts once)
         off = self._off[:n + 1]
         ctx.d2h(off, d["offsets"])
         ctx.synchronize()
@@ -198,6 +209,11 @@ class SparseLoop(object):
             pending = []
             for k, i0 in enumerate(starts):
                 m = enqueue(i0, outs[k % 3])
+                if k == 0 and self.guard.enabled and not self.guard.checks:
+                    # first batch of this loop's life: one stream synchronisation (~ a batch) to read the saturation word before anything is fetched
+                    if self.guard.check("SparseLoop.run_many") is not None:
+                        m = enqueue(i0, outs[0])               # premultipliers recalibrated on this batch: redo it
+                        ctx.numeric_status()
                 ctx.mark(k % 3)
                 pending.append((i0, m, outs[k % 3], k % 3))
                 if len(pending) == 3:
@@ -205,6 +221,10 @@ class SparseLoop(object):
             for item in pending:
                 fetch(*item)
             ctx.synchronize()                    # surfaces the ray-pooling range error, if any
+            if self.guard.checks and self.guard.check("SparseLoop.run_many, later batches") is not None:
+                # a batch after the first saturated codes for the first time: the premultipliers are recalibrated (on the call's last batch) for what
+                # follows; this call's results stand - a saturated value loses its own correction term only
+                ctx.numeric_status()
         finally:
             for p in (gp, gx, gr, gw):
                 ctx.dev_free(p)
@@ -359,7 +379,7 @@ _LOOP_EMPTY = dict(prediction_list=[], rgb_list=[], vxl_ijk_list=[], rayPooling_
 
 
 def scene_cube_loop(images_list, cameraPOs_np, valid_cubes_param_np, viewPairs4Reconstr, w_viewPairs4Reconstr, cube_D, N_viewPairs4inference,
-                    cube_Dcenter, batchSize_nViewPair_SurfaceNet=None, min_prob=0.46, tau=0.7, gamma=0.8, ctx=None, timings=None):
+                    cube_Dcenter, batchSize_nViewPair_SurfaceNet=None, min_prob=0.46, tau=0.7, gamma=0.8, ctx=None, timings=None, auto_calibrate=True):
     """main_reconstruct.py:126-173 for a run of VALID cubes (their rows of the cube table, their selected view pairs and weights): per batch
     CVC, SurfaceNet, fusion, voxel colours, ray pooling, dense2sparse - device-resident (`SparseLoop.run_many`) - then the thinning masks.
     Returns prediction_list, rgb_list, vxl_ijk_list, rayPooling_votes_list, vxl_mask_list, param_np, viewPair_np, cube_ijk_np (rows of the
@@ -375,7 +395,7 @@ def scene_cube_loop(images_list, cameraPOs_np, valid_cubes_param_np, viewPairs4R
     bs = int(batchSize_nViewPair_SurfaceNet or max(1, ctx.max_samples // N_vp))
     bs = min(bs, max(1, ctx.max_samples // N_vp))
     loop = SparseLoop(ctx, N_vp, max_cubes=bs, min_prob=min_prob, rayPool_thresh=0, enable_centerCrop=True, cube_Dcenter=cube_Dcenter,
-                      enable_rayPooling=True)
+                      enable_rayPooling=True, auto_calibrate=auto_calibrate)
     try:
         # the batches of gen_non0Batch_npBool(validCubes, bs) are consecutive runs of valid cubes: run_many walks exactly those
         nonempty, ijk_l, p_l, rgb_l, v_l, xyz_new = loop.run_many(viewPairs4Reconstr, valid_cubes_param_np['xyz'], valid_cubes_param_np['resol'],
@@ -396,7 +416,7 @@ def scene_cube_loop(images_list, cameraPOs_np, valid_cubes_param_np, viewPairs4R
 
 _SELECT_KEYS = ("patch2embedding_fn", "embeddingPair2simil_fn", "viewPair_relativeImpt_fn", "patches_mean_bgr", "batchSize_similNet_patch2embedding",
                 "batchSize_similNet_embeddingPair2simil", "batchSize_viewPair_w", "weighted_fusion", "D_embedding", "patchSize")
-_LOOP_KEYS = ("cube_Dcenter", "batchSize_nViewPair_SurfaceNet", "min_prob", "tau", "gamma")
+_LOOP_KEYS = ("cube_Dcenter", "batchSize_nViewPair_SurfaceNet", "min_prob", "tau", "gamma", "auto_calibrate")
 
 
 def _split_scene_kw(kw):
@@ -411,7 +431,7 @@ def _split_scene_kw(kw):
 def reconstruct_scene(images_list, cameraPOs_np, cubes_param_np, cube_D_mm, cube_D, N_viewPairs4inference, patch2embedding_fn, embeddingPair2simil_fn,
                       viewPair_relativeImpt_fn, cube_Dcenter, patches_mean_bgr, batchSize_similNet_patch2embedding=100,
                       batchSize_similNet_embeddingPair2simil=100000, batchSize_viewPair_w=100000, batchSize_nViewPair_SurfaceNet=None,
-                      weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64, ctx=None, timings=None):
+                      weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64, ctx=None, timings=None, auto_calibrate=True):
     """The body of main_reconstruct.reconstruction() between file input and PLY output (main_reconstruct.py:67-173):
     corner / centre projections -> early rejection (similarityNet) -> view-pair selection (relative-weight MLP) ->
     per batch: CVC, SurfaceNet, fusion, voxel colours, ray pooling, dense2sparse -> thinning masks  (= `scene_select` + `scene_cube_loop`).
@@ -524,7 +544,7 @@ def reconstruct_scene_sharded(images_list, cameraPOs_np, cubes_param_np, cube_D_
                               batchSize_similNet_patch2embedding=100, batchSize_similNet_embeddingPair2simil=100000, batchSize_viewPair_w=100000,
                               batchSize_nViewPair_SurfaceNet=None, weighted_fusion=True, min_prob=0.46, tau=0.7, gamma=0.8, D_embedding=128, patchSize=64,
                               ctx=None, timings=None, group=None, comm_device=None, comm="auto", world=None, rank=None, select_fn=None, loop_fn=None,
-                              gather_intermediates=False):
+                              gather_intermediates=False, auto_calibrate=True):
     """`reconstruct_scene` over the ranks of a job (one process per GPU; weights / images / cameras replicated).
 
     Stage 1 - early rejection and view-pair selection (`scene_select`) - is sharded by RAW cube range: its cost is per cube (V patches each),

@@ -60,3 +60,34 @@ def toy_pair_simil(emb_pairs):
     e = np.asarray(emb_pairs, dtype=np.float64).reshape(-1, 2, emb_pairs.shape[-1])
     d = np.asarray([math.fsum(np.abs(a - b)) for a, b in e])
     return (d / (d + 300.0)).astype(np.float32)[:, None]
+
+
+def cvc_config_cases():
+    """CVC cases AT THE SIZES OF BASELINE.json's configs (oracle/gen_golden_configs.py ran the reference's CVC.py on them): name -> (scene dict, s,
+    digest dict: sha256, idx, val, chan_sum, shape, inscope)."""
+    import hashlib
+    from surfacenet_amd import synthetic
+    z = np.load(os.path.join(GOLDEN, "cvc_config_cases.npz"))
+    out = {}
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        c = {k.split("/")[1]: z[k] for k in z.files if k.startswith(name + "/")}
+        s = int(c["s"])
+        if name == "edge_s64":
+            sc = synthetic.synthetic_scene(2, 3, s=64, seed=5)
+            sc["xyz"], sc["resol"] = c["xyz"], c["resol"]
+            assert np.array_equal(sc["pairs"], c["pairs"])
+        else:
+            sc = synthetic.synthetic_scene(int(c["n"]), int(c["n_vp"]), s=s, seed=int(c["seed"]))
+        out[name] = (sc, s, c)
+    return out
+
+
+def check_cvc_digest(out_f32, c):
+    """out_f32: a (N, 6, s, s, s) float32 CVC tensor (raw colours) vs the digest of the reference's output."""
+    import hashlib
+    assert out_f32.dtype == np.float32 and tuple(out_f32.shape) == tuple(int(v) for v in c["shape"])
+    u8 = out_f32.astype(np.uint8)
+    assert np.array_equal(u8.astype(np.float32), out_f32)                            # integer-valued 0..255
+    assert np.array_equal(u8.reshape(-1)[c["idx"]], c["val"])
+    assert np.array_equal(u8.reshape(u8.shape[0], 6, -1).sum(axis=2, dtype=np.int64), c["chan_sum"])
+    assert hashlib.sha256(np.ascontiguousarray(u8).tobytes()).digest() == bytes(c["sha256"])      # every voxel of every sample

@@ -294,3 +294,96 @@ def test_sharded_scene_failure_on_one_rank_raises_everywhere_gloo():
     res = _run_scene_ranks(11, "raise", 39500)
     for rank, full, counts in res:
         assert isinstance(full, str) and "cube loop failed on rank 1" in full and "SN_ERR_RANGE stand-in" in full, full
+
+
+class _GlooNativeStandIn(object):
+    """CPU stand-in of a Context whose communicator is up, for the protocol of `Context.allgatherv_bytes` (`context.allgatherv_two_step`):
+    the two C entry points are restated over gloo EXACTLY as sn_api.hip runs them - sn_allgatherv_counts = one 8-byte all-gather;
+    sn_allgatherv_bytes_dev = the counts all-gather, then the payload all-gather padded to the largest contribution, the destination size checked
+    only afterwards - and every collective first all-gathers its own (kind, size) tag, so that ranks issuing DIFFERENT collectives at the same
+    step (the hang / corruption of ADVICE r4) fail the test instead of blocking it."""
+
+    def __init__(self, dist, world, rank):
+        self.dist, self.comm_world, self.comm_rank, self.log = dist, world, rank, []
+
+    def _collective(self, kind, nbytes, payload):
+        import torch
+        tags = [None] * self.comm_world
+        self.dist.all_gather_object(tags, (kind, int(nbytes)))
+        assert len(set(tags)) == 1, "ranks disagree on the collective at this step: %r" % (tags,)
+        self.log.append((kind, int(nbytes)))
+        out = torch.empty((self.comm_world * nbytes,), dtype=torch.uint8)
+        buf = torch.zeros((nbytes,), dtype=torch.uint8)
+        buf[: payload.size] = torch.from_numpy(np.ascontiguousarray(payload))
+        self.dist.all_gather_into_tensor(out, buf)
+        return out.numpy().reshape(self.comm_world, nbytes)
+
+    def _counts(self, n_local):
+        rows = self._collective("counts", 8, np.frombuffer(np.asarray([n_local], np.uint64).tobytes(), np.uint8))
+        return [int(np.frombuffer(r.tobytes(), np.uint64)[0]) for r in rows]
+
+    def allgatherv_bytes(self, blob):
+        from surfacenet_amd import context
+        blob = np.ascontiguousarray(np.asarray(blob, np.uint8).reshape(-1))
+
+        def payload_fn(n_local, total):
+            counts = self._counts(n_local)
+            if sum(counts) == 0:
+                return counts, np.empty((0,), np.uint8)
+            cap = (max(counts) + 15) & ~15
+            rows = self._collective("payload", cap, blob)
+            assert total >= sum(counts), "destination too small: reported only AFTER the payload collective"
+            return counts, np.concatenate([rows[r, : counts[r]] for r in range(self.comm_world)])
+        return context.allgatherv_two_step(int(blob.size), self._counts, payload_fn)
+
+
+def _allgatherv_worker(rank, world, port, sizes, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from surfacenet_amd import reconstruct
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _GlooNativeStandIn(dist, world, rank)
+    out = []
+    for step, per_rank in enumerate(sizes):
+        blob = (np.arange(per_rank[rank], dtype=np.int64) * 7 + 13 * rank + step).astype(np.uint8)
+        parts = ctx.allgatherv_bytes(blob)
+        out.append([bytes(p) for p in parts])
+    # the error path of the scene exchange: rank 1's stage raises (a short error string against rank 0's 3 MB payload)
+    def stage():
+        if rank == 1:
+            raise RuntimeError("SN_ERR_RANGE stand-in")
+        return np.full((3 << 20,), 5, np.uint8)
+    try:
+        reconstruct._exchange("cube loop", stage, ctx=ctx)
+        err = None
+    except RuntimeError as e:
+        err = str(e)
+    q.put((rank, out, err, ctx.log))
+    dist.destroy_process_group()
+
+
+def test_native_allgatherv_protocol_very_unequal_blobs_gloo():
+    """the first allgatherv_bytes sized its destination from the rank's OWN blob and retried alone when the C call said "too
+    small" - a rank with a small blob then issued a counts all-gather against its peers' payload all-gather. Now the sequence is the same on
+    every rank (counts; counts + payload) whatever the sizes: 3 bytes against 2 MB, an empty blob, all empty, and the error path of `_exchange`."""
+    import torch.multiprocessing as mp
+    sizes = [(3, 2 << 20), (1 << 20, 0), (0, 0), (17, 17)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 41000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_allgatherv_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][3] == res[1][3]              # same bytes, same collective sequence on both ranks
+    for step, per_rank in enumerate(sizes):
+        for r in range(2):
+            want = (np.arange(per_rank[r], dtype=np.int64) * 7 + 13 * r + step).astype(np.uint8).tobytes()
+            assert res[0][1][step][r] == want
+    for rank, _, err, log in res:
+        assert err is not None and "cube loop failed on rank 1" in err and "SN_ERR_RANGE stand-in" in err, err
+        assert [k for k, _ in log] == ["counts", "counts", "payload"] * 2 + ["counts", "counts"] + ["counts", "counts", "payload"] * 2

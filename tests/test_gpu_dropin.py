@@ -188,3 +188,104 @@ def test_inference_entry_points_read_python2_model_files(dropin, tmp_path, proto
     ref_emb = simil_oracle.embedding_torch(patches, svals, dtype="float64")
     print("protocol %d: similarityNet from file, embedding L_inf vs fp64 oracle %.3e" % (proto, float(np.abs(emb - ref_emb).max())))
     assert emb.shape == (5, 128) and np.abs(emb - ref_emb).max() < 1e-4
+
+
+def _wide_net(spread):
+    """A BN-calibrated net whose merge_conv_a BatchNorm under-estimates the spread of its pre-activations `spread`-fold (function unchanged: the fp64
+    oracle of the plain net is the reference) - the stress case of tests/test_gpu_numerics.py, here fed through the DROP-IN callables."""
+    import synth
+    from surfacenet_amd import weights
+    ix = {(layer, p): i for i, (layer, p, _) in enumerate(weights.PARAM_LAYOUT)}
+    values = [np.array(v) for v in synth.calibrated_params(2)]
+    values[ix[("merge_conv_a", "inv_std")]] *= np.float32(spread)
+    return values
+
+
+@pytest.mark.parametrize("spread,tol", [(3.2, 2e-4), (10.0, 1e-3)])
+def test_dropin_callables_calibrate_saturating_nets_and_warn_once(dropin, spread, tol):
+    """the numerics safety net must reach the caller who holds real weights (nets/SurfaceNet.py:385-402, main_reconstruct.py:145-146).
+    `nViewPair_SurfaceNet_fn` reads the saturation warning after the batch, recalibrates the 6-bit premultipliers on it, redoes it and emits exactly
+    ONE RuntimeWarning (layer name + exponents); later calls stay silent. x3.2: within the default tolerance 2e-4; x10: within the 1e-3 bar
+    (uncalibrated: 1.35e-3). auto_calibrate=False keeps the static exponents (no warning, the graceful degradation of DESIGN 5.1)."""
+    import warnings
+    import synth
+    from oracle import net_oracle
+    _, SurfaceNet, runtime = dropin
+    s, n, n_vp = 16, 2, 2
+    values = _wide_net(spread)
+    X = synth.random_cvc(n * n_vp, s, 31)
+    w = (np.random.RandomState(2).rand(n, n_vp) + 0.1).astype(np.float32)
+    f64, u64 = net_oracle.forward_torch(X, values, w=w, n_vp=n_vp)
+    _, fn = SurfaceNet.SurfaceNet_inference(n_vp, None, param_values=values)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        fused, unfused = fn(X, w)
+        fused2, unfused2 = fn(X, w)                    # the second call: calibrated already, silent
+    msgs = [str(r.message) for r in rec if issubclass(r.category, RuntimeWarning)]
+    assert len(msgs) == 1 and "merge_conv_a" in msgs[0] and "s_act 0 ->" in msgs[0], msgs
+    e = float(np.abs(unfused - u64).max())
+    print("   spread x%.1f through nViewPair_SurfaceNet_fn: L_inf %.3e (tolerance %.0e); warning: %s" % (spread, e, tol, msgs[0][:160]))
+    assert e < tol and np.abs(fused - f64).max() < tol
+    assert np.array_equal(unfused, unfused2) and np.array_equal(fused, fused2)
+    # opt-out: static exponents, no warning
+    runtime.reset()
+    _, fn0 = SurfaceNet.SurfaceNet_inference(n_vp, None, param_values=values, auto_calibrate=False)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        _, unf0 = fn0(X, w)
+    assert not [r for r in rec if issubclass(r.category, RuntimeWarning)]
+    e0 = float(np.abs(unf0 - u64).max())
+    print("   ... with auto_calibrate=False: L_inf %.3e" % e0)
+    assert e0 > e
+
+
+def test_hot_loop_and_sparse_loop_calibrate_on_their_first_batch(dropin):
+    """The same through reconstruct.hot_loop (generator over batches) and reconstruct.SparseLoop.run / run_many (device-resident loop body): the first
+    batch is checked, recalibrated and redone; one warning per loop; results equal a context calibrated by hand on that batch."""
+    import warnings
+    import surfacenet_amd
+    from surfacenet_amd import reconstruct
+    s, n_all, n_vp = 16, 7, 2
+    values = _wide_net(10.0)
+    sc = golden_util.synthetic_scene(n_all, n_vp, s=s, seed=4, hw=(600, 800))
+    cubes_param_np = np.zeros(n_all, dtype=[("xyz", np.float32, (3,)), ("ijk", np.uint32, (3,)), ("resol", np.float32)])
+    cubes_param_np["xyz"], cubes_param_np["resol"] = sc["xyz"], sc["resol"]
+    valid = np.ones(n_all, dtype=bool)
+
+    def fresh():
+        ctx = surfacenet_amd.Context(cube_D=s, max_samples=8)
+        ctx.load_param_values(values); ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        return ctx
+    # reference: calibrate by hand on the first batch (3 cubes), then run everything
+    with fresh() as ctx:
+        ctx.cvc_forward(sc["pairs"][:3], sc["xyz"][:3], sc["resol"][:3], sc["w"][:3])
+        assert ctx.numeric_status() == ["merge_conv_a"]
+        ctx.calibrate(0)
+        want = [ctx.cvc_forward(sc["pairs"][i:i + 3], sc["xyz"][i:i + 3], sc["resol"][i:i + 3], sc["w"][i:i + 3])[0] for i in range(0, n_all, 3)]
+        loop = reconstruct.SparseLoop(ctx, n_vp, max_cubes=3, min_prob=0.5, cube_Dcenter=12, auto_calibrate=False)
+        want_sparse = loop.run_many(sc["pairs"], sc["xyz"], sc["resol"], sc["w"])
+        loop.close()
+    with fresh() as ctx, warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = [f for _, f, _, _ in reconstruct.hot_loop(ctx, valid, sc["pairs"], sc["w"], cubes_param_np, batch_size=3, return_cvc=False)]
+        assert len([r for r in rec if issubclass(r.category, RuntimeWarning)]) == 1
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    with fresh() as ctx, warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        loop = reconstruct.SparseLoop(ctx, n_vp, max_cubes=3, min_prob=0.5, cube_Dcenter=12)
+        got_sparse = loop.run_many(sc["pairs"], sc["xyz"], sc["resol"], sc["w"])
+        first = loop.run(sc["pairs"][:3], sc["xyz"][:3], sc["resol"][:3], sc["w"][:3])     # calibrated already: silent
+        loop.close()
+        assert len([r for r in rec if issubclass(r.category, RuntimeWarning)]) == 1
+    assert got_sparse[0] == want_sparse[0] and len(got_sparse[0]) > 0
+    for k in (1, 2, 3, 4):
+        assert all(np.array_equal(a, b) for a, b in zip(got_sparse[k], want_sparse[k]))
+    assert first[0] == [i for i in want_sparse[0] if i < 3]
+    with fresh() as ctx, warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        loop = reconstruct.SparseLoop(ctx, n_vp, max_cubes=3, min_prob=0.5, cube_Dcenter=12)
+        one = loop.run(sc["pairs"][:3], sc["xyz"][:3], sc["resol"][:3], sc["w"][:3])       # run(): warns, recalibrates, redoes
+        loop.close()
+        assert len([r for r in rec if issubclass(r.category, RuntimeWarning)]) == 1
+    assert one[0] == first[0] and all(np.array_equal(a, b) for a, b in zip(one[2], first[2]))

@@ -271,3 +271,41 @@ def test_nan_and_negative_overflow_fail_loudly(sn):
     bad[ix[("conv3_2", "inv_std")]][7] = np.float32(3e38)       # folded scale finite (-3e38); accumulator * scale = -+inf: -inf -> ReLU -> 0
     with pytest.raises(sn.SurfaceNetHipError, match="conv3_2"):
         _run(sn, bad, X, w, s, n_vp)
+
+
+def test_non_finite_batchnorm_constants_are_rejected_at_load(sn):
+    """The stored-value tracker of the store epilogues is a packed MAX, which drops a quiet NaN: a stored NaN whose accumulator was
+    finite - sigmoid(NaN) from a NaN folded scale / shift of a side convolution - would not raise the status bit. It cannot get that far: every
+    non-finite folded BatchNorm constant fails sn_load_weights, naming the layer."""
+    values, X, w, s, n, n_vp = _case(1)
+    ix = _index()
+    for layer, param, val in (("side_op1", "gamma", np.nan), ("side_op3", "beta", np.nan), ("conv2_2", "inv_std", np.inf), ("merge_conv3", "mean", np.nan)):
+        bad = [np.array(v) for v in values]
+        bad[ix[(layer, param)]][0] = np.float32(val)
+        with sn.Context(cube_D=s, max_samples=4) as ctx:
+            with pytest.raises(sn.SurfaceNetHipError, match=layer):
+                ctx.load_param_values(bad)
+
+
+def test_calibrate_refuses_stale_or_foreign_activations(sn):
+    """sn_calibrate_dev scans what the LAST forward call left in the workspace: it must refuse a fresh context (a zeroed workspace would
+    set both exponents to +6), more samples than that call ran (older data), and the all-MX mode, whose single activation exponent also belongs to
+    tensors the pooling / upsampling kernels decode with the static one."""
+    values, X, w, s, n, n_vp = _case(1)
+    with sn.Context(cube_D=s, max_samples=8) as ctx:
+        ctx.load_param_values(values)
+        with pytest.raises(sn.SurfaceNetHipError, match="no forward call"):
+            ctx.calibrate(2)
+        ctx.forward(X[:2], None, n_vp=1)
+        with pytest.raises(sn.SurfaceNetHipError, match="ran 2 samples"):
+            ctx.calibrate(4)
+        cal = ctx.calibrate(2)
+        assert -6 <= cal["s_act"] <= 6 and -6 <= cal["s_cat"] <= 6
+        ctx.load_param_values(values)                                  # new weights: the workspace is stale again
+        with pytest.raises(sn.SurfaceNetHipError, match="no forward call"):
+            ctx.calibrate(2)
+    with sn.Context(cube_D=s, max_samples=8, precision="f16m8") as ctx:
+        ctx.load_param_values(values)
+        ctx.forward(X[:2], None, n_vp=1)
+        with pytest.raises(sn.SurfaceNetHipError, match="default precision mode"):
+            ctx.calibrate(2)

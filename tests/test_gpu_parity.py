@@ -31,6 +31,18 @@ def test_cvc_warp_bit_exact_vs_reference_golden(sn, name):
     assert np.array_equal(out, c["out_u8"].astype(np.float32))
 
 
+@pytest.mark.parametrize("name", ["cfg1_s32", "cfg3_s64", "edge_s64"])
+def test_cvc_warp_bit_exact_at_the_configs_own_sizes(sn, name):
+    """The HIP warp on BASELINE configs[1]'s own synthetic scene (full 1200x1600 frames, s = 32), configs[3]'s (s = 64) and an s = 64 cube pair with
+    out-of-scope voxels, against digests of what the reference's CVC.py returned for them (oracle/gen_golden_configs.py; VERDICT r4: the one link
+    missing between "the oracle is pinned" and "the kernel is checked against the oracle at the configs' sizes")."""
+    sc, s, c = golden_util.cvc_config_cases()[name]
+    with sn.Context(cube_D=s, max_samples=8) as ctx:
+        ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        out = ctx.cvc(sc["pairs"], sc["xyz"], sc["resol"])
+    golden_util.check_cvc_digest(out, c)
+
+
 @pytest.mark.parametrize("name", ["dtu_real", "mid_real"])
 def test_real_dataset_pixels_cvc_bit_exact_and_cnn_parity(sn, name):
     """Real DTU scan9 / Middlebury dino pixels (tests/golden/real_cases.npz, written by executing the reference's CVC.py on decoded windows

@@ -108,3 +108,15 @@ def test_color_fusion_golden():
     X += golden_util.MEAN6[None, :, None, None, None]                 # what the caller holds at main_reconstruct.py:150
     rgb = cvc_oracle.color_fuse(X, z["pred"], z["w"])
     assert rgb.dtype == np.uint8 and np.array_equal(rgb, z["rgb"])
+
+
+@pytest.mark.parametrize("name", ["cfg1_s32", "cfg3_s64", "edge_s64"])
+def test_c_oracle_at_the_configs_own_sizes(name):
+    """the C oracle was pinned at s <= 32 on hand-placed cubes only. Here: BASELINE configs[1]'s own synthetic scene (full 1200x1600
+    frames, s = 32), configs[3]'s (s = 64) and an s = 64 cube pair with out-of-scope voxels, against digests (sha256 over every voxel + 4,096
+    sampled values + per-channel sums) of what the reference's own CVC.py returned for them (oracle/gen_golden_configs.py)."""
+    sc, s, c = golden_util.cvc_config_cases()[name]
+    out = cvc_oracle.gen_coloredCubes(sc["pairs"], sc["xyz"], sc["resol"], sc["cams"], sc["imgs"], s)
+    golden_util.check_cvc_digest(out, c)
+    if name == "edge_s64":
+        assert 0.2 < float(c["inscope"]) < 0.8                   # the case really has out-of-scope voxels

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""tools/format_table.py — per-layer correction-format table of the default mode, evaluated on the CPU model of the device arithmetic
+(oracle/net_emulation.py; TEST INFRASTRUCTURE): for each candidate assignment {layer -> x3 | m6 | m8} the modelled L_inf of the surface
+probabilities against the fp64 oracle, on the noise inputs of the parity tests (seeds 32-34: tests/test_gpu_parity.py::_net_case) and, with
+--structured, on the structured inputs of tests/test_gpu_numerics.py. MFMA units per product: x3 = 3, m8 = 2, m6 = 1.5.
+
+    python tools/format_table.py [--s 32] [--seeds 32,33,34] [--only NAME,...] [--structured] [--out profiles/r5/format_table.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+C1 = ["conv1_1", "conv1_2", "conv1_3"]
+C2 = ["conv2_1", "conv2_2", "conv2_3"]
+C3 = ["conv3_1", "conv3_2", "conv3_3"]
+C4 = ["conv4_1", "conv4_2", "conv4_3"]
+MG = ["merge_conv_a", "merge_conv_b"]
+
+
+def tab(**kw):
+    t = {}
+    for fmt, layers in kw.items():
+        for l in layers:
+            t[l] = fmt
+    return t
+
+
+CANDIDATES = {
+    "shipped_r4 (merge m6)": ({}, {}),
+    "conv4 m8": (tab(m8=C4), {}),
+    "conv4 m8 s8=2": (tab(m8=C4), {"s8_act": 2}),
+    "conv4_2,4_3 m8": (tab(m8=C4[1:]), {}),
+    "conv4 m6": (tab(m6=C4), {}),
+    "conv4+conv3 m8": (tab(m8=C4 + C3), {}),
+    "conv4+conv3+conv2 m8": (tab(m8=C4 + C3 + C2), {}),
+    "conv4+conv3+conv2+conv1_2,1_3 m8": (tab(m8=C4 + C3 + C2 + C1[1:]), {}),
+    "merge m8 (rest x3)": (tab(m8=MG), {}),
+    "merge m8 + conv4 m8": (tab(m8=MG + C4), {}),
+    "all x3 (f16x3p)": (tab(x3=MG), {}),
+}
+MACS = {"conv1_1": 169869312, "conv1_2": 905969664, "conv1_3": 905969664, "conv2_1": 283115520, "conv2_2": 707788800, "conv2_3": 707788800,
+        "conv3_1": 176947200, "conv3_2": 353894400, "conv3_3": 353894400, "conv4_1": 663552000, "conv4_2": 1244160000, "conv4_3": 1244160000,
+        "merge_conv_a": 5662310400, "merge_conv_b": 8847360000}
+UNITS = {"x3": 3.0, "m8": 2.0, "m6": 1.5}
+
+
+def mfma_units(table):
+    from oracle import net_emulation
+    f = dict(net_emulation.LAYER_FORMATS_DEFAULT)
+    f.update(table)
+    return sum(MACS[l] * UNITS[f[l]] for l in MACS) / sum(MACS.values())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--s", type=int, default=32)
+    ap.add_argument("--n-vp", type=int, default=3)
+    ap.add_argument("--seeds", default="32,33,34")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--structured", action="store_true")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    import synth
+    from oracle import net_emulation, net_oracle
+    names = [n for n in CANDIDATES if not args.only or any(o in n for o in args.only.split(","))]
+    rows = {n: {"units_per_product": round(mfma_units(CANDIDATES[n][0]), 4), "linf": {}} for n in names}
+    cases = []
+    for seed in [int(x) for x in args.seeds.split(",")]:
+        values = list(synth.calibrated_params(seed % 3))
+        X = synth.random_cvc(args.n_vp, args.s, seed + 10)
+        cases.append(("noise seed %d" % seed, values, X))
+    if args.structured:
+        import test_gpu_numerics as tn
+        values = list(synth.calibrated_params(0))
+        for label, X in tn._structured_inputs(args.s, 5).items():
+            cases.append((label, values, X))
+    for label, values, X in cases:
+        t0 = time.time()
+        _, u64 = net_oracle.forward_torch(X, values, n_vp=1)
+        print("== %s: oracle %.0f s" % (label, time.time() - t0), flush=True)
+        for n in names:
+            table, kw = CANDIDATES[n]
+            t0 = time.time()
+            _, ue = net_emulation.forward_emulated(X, values, n_vp=1, mode="f16x3", table=table, **kw)
+            e = float(np.abs(ue - u64).max())
+            rows[n]["linf"][label] = e
+            print("  %-40s units %.3f  L_inf %.3e  (%.0f s)" % (n, rows[n]["units_per_product"], e, time.time() - t0), flush=True)
+        if args.out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+            json.dump({"s": args.s, "cases": [c[0] for c in cases], "rows": rows}, open(args.out, "w"), indent=1)
+    print("== worst case per assignment")
+    for n in names:
+        print("  %-40s units %.3f  max L_inf %.3e" % (n, rows[n]["units_per_product"], max(rows[n]["linf"].values())))
+
+
+if __name__ == "__main__":
+    main()
