@@ -22,7 +22,8 @@ from those codes, already differs in 2.9 % of its fp16 values and 11 % of its lo
 the device's error, correlation 0.82 between the two error fields) is this sensitivity, not a modelling gap: every parameter variant
 tried (premultipliers, lo exponent, block shape, renormalisation on / off) lowers the correlation.
 mode "f16x3" (the default): everything "x3" except the concat buffer and merge_conv_a's output (storage m6, premultipliers s = 2 / 0)
-and merge_conv_a / merge_conv_b (product m6); conv1_3 / conv2_3 feed their side conv and pool from unrounded registers.
+and merge_conv_a / merge_conv_b (product m6) and - round 5 - the dilated chain conv4_1 .. conv4_3 (product m6 on code planes with s = -1; conv3_3's
+code plane is derived from its stored hi / lo planes); conv1_3 / conv2_3 feed their side conv and pool from unrounded registers.
 mode "f16m8": every tensor m6, every conv product m6 (the network input with s = -5).
 Round 5: a per-layer CORRECTION-FORMAT TABLE for the default mode (`table`, layer name -> "x3" | "m6" | "m8"; LAYER_FORMATS_DEFAULT is what
 the library ships) answers "which 3x3x3 layers may leave the three-fp16-MFMA arithmetic at an unchanged tolerance" without a GPU:
@@ -42,6 +43,8 @@ S8_ACT = 0
 LAYER_FORMATS_DEFAULT = {"conv1_1": "x3", "conv1_2": "x3", "conv1_3": "x3", "conv2_1": "x3", "conv2_2": "x3", "conv2_3": "x3",
                          "conv3_1": "x3", "conv3_2": "x3", "conv3_3": "x3", "conv4_1": "x3", "conv4_2": "x3", "conv4_3": "x3",
                          "merge_conv_a": "m6", "merge_conv_b": "m6"}
+S_C4 = -1                    # premultiplier of the code planes the conv4 chain reads when it runs on the fp6 MX step (conv3_3's, conv4_1's, conv4_2's outputs;
+S6_OF_DEFAULT = {"conv3_3": S_C4, "conv4_1": S_C4, "conv4_2": S_C4}      # mx_format.h SN_MX_S_C4): applies to table entries conv4_x = "m6" / "b6" only
 
 
 def _ilogb(a):
@@ -63,8 +66,10 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act
     P = net_oracle.params_to_dict(values)
     full = mode == "f16m8"
     fmt_of = dict(LAYER_FORMATS_DEFAULT)
+    s6_tab = {} if full else dict(S6_OF_DEFAULT)
+    s6_tab.update(s6_of or {})
     if table:
-        assert not full and set(table) <= set(fmt_of) and set(table.values()) <= {"x3", "m6", "m8"}, table
+        assert not full and set(table) <= set(fmt_of) and set(table.values()) <= {"x3", "m6", "m8", "b6"}, table
         fmt_of.update(table)
 
     def f16(t):
@@ -84,21 +89,31 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act
         step = torch.exp2(e - 3)
         return (torch.sign(v) * torch.round(a / step) * step).clamp(min=-448.0, max=448.0)
 
-    QF = {"m6": (q6, LO_EXP, 7.5), "m8": (q8, LO_EXP8, 448.0)}
+    def qb6(v):
+        """bf6 e3m2 of v: RNE, saturating at 28, subnormal step 2^-4 below 2^-2."""
+        a = v.abs().clamp(max=28.0)
+        e = torch.floor(torch.log2(torch.clamp(a, min=0.25)))
+        e = e + (torch.exp2(e + 1) <= a).to(td) - (torch.exp2(e) > torch.clamp(a, min=0.25)).to(td)
+        step = torch.exp2(e - 2)
+        return (torch.sign(v) * torch.round(a / step) * step).clamp(min=-28.0, max=28.0)
+
+    QF = {"m6": (q6, LO_EXP, 7.5), "m8": (q8, LO_EXP8, 448.0), "b6": (qb6, LO_EXP, 28.0)}
 
     class T:  # an activation tensor: the producer's fp32 result in ORIGINAL units + how its readers see what the device stores
-        def __init__(self, v, oe, s6=S_ACT, s8=None):
+        def __init__(self, v, oe, s6=S_ACT, s8=None, via16=False):
+            self.via16 = via16
             self.oe = torch.from_numpy(np.asarray(oe, dtype=np.float64)).view(1, -1, 1, 1, 1)      # stored = v * 2^oe
             self.r = v * torch.exp2(self.oe)
             self.hi = f16(self.r)
-            self.s = {"m6": s6, "m8": s8_act if s8 is None else s8}
+            self.s = {"m6": s6, "b6": s6, "m8": s8_act if s8 is None else s8}
 
         def lo(self, fmt):                       # the stored residual as a reader of format fmt reconstructs it
             if fmt == "x3":
                 return f16(self.r - self.hi)
             q, le, _ = QF[fmt]
             k = 2.0 ** (le + self.s[fmt])
-            return q((self.r - self.hi) * k) / k
+            res = self.r - self.hi
+            return q((f16(res) if self.via16 else res) * k) / k
 
         def hi_q(self, fmt):                     # the code of hi that multiplies the weights' lo parts
             q, _, _ = QF[fmt]
@@ -193,7 +208,9 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act
             m = np.maximum(np.abs(p["gamma"].astype(np.float64)), np.abs(p["beta"].astype(np.float64)))
             oe = np.clip(-_ilogb(m), -60, 60).astype(np.float64)
             oe[~(m > 0)] = 0
-        return T(y, oe, (s6_of or {}).get(name, s6_out))       # s6_of: what-if premultipliers of a layer's OUTPUT tensor (fp6 readers)
+        # s6_of: what-if premultipliers of a layer's OUTPUT tensor (fp6 readers). conv3_3's code plane is derived from its stored (hi, lo) fp16 planes
+        # (x3_to_m6_kernel: side_op3 reads those), every other code plane straight from the fp32 result
+        return T(y, oe, s6_tab.get(name, s6_out), via16=(name == "conv3_3" and not full and fmt_of["conv4_1"] != "x3"))
 
     def up(x, name, f):
         k = P[name]["W"].shape[2]
@@ -212,13 +229,13 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act
     y13 = c13.r / torch.exp2(c13.oe)
     # conv1_3 / conv2_3: side conv and pool run on the unrounded registers; the pooled tensor is stored in the format its reader asks for
     s1 = conv(y13, "side_op1", "conv1", "sigmoid", "x3", raw_out=True)
-    p1 = T(F.max_pool3d(y13, 2, 2), c13.oe.view(-1).numpy())
+    p1 = T(F.max_pool3d(y13, 2, 2), c13.oe.view(-1).numpy(), s6_tab.get("pool1", S_ACT))
     c21 = conv(p1, "conv2_1", "conv3", "relu", f("conv2_1"))
     c22 = conv(c21, "conv2_2", "conv3", "relu", f("conv2_2"))
     c23 = conv(c22, "conv2_3", "conv3", "relu", f("conv2_3"))
     y23 = c23.r / torch.exp2(c23.oe)
     s2 = T(conv(y23, "side_op2", "conv1", "sigmoid", "x3", raw_out=True), np.zeros(16))
-    p2 = T(F.max_pool3d(y23, 2, 2), c23.oe.view(-1).numpy())
+    p2 = T(F.max_pool3d(y23, 2, 2), c23.oe.view(-1).numpy(), s6_tab.get("pool2", S_ACT))
     c31 = conv(p2, "conv3_1", "conv3", "relu", f("conv3_1"))
     c32 = conv(c31, "conv3_2", "conv3", "relu", f("conv3_2"))
     c33 = conv(c32, "conv3_3", "conv3", "relu", f("conv3_3"))

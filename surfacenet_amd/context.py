@@ -27,13 +27,13 @@ class NumericsGuard(object):
     as fp16 + 6-bit codes under per-tensor premultipliers that are static - sized from the BatchNorm parameters a trained net obeys. A net that does
     not obey them saturates codes (each such value loses its own correction term); the library raises a WARNING word for that (`numeric_status`) and
     can derive the premultipliers from data instead (`calibrate`). `check()` - called by the caller right after its first batch, then once per
-    scene / per call - reads the word; on the first saturation report it calibrates on the batch that was just run, emits ONE `RuntimeWarning`
+    scene / per call - reads the word; when more than `trigger_fraction` of a code plane's values saturate it calibrates on the batch that was just run, emits ONE `RuntimeWarning`
     naming the layers and the exponents chosen, and returns the calibration report: the caller then REDOES that batch (nets/SurfaceNet.py:385-402
     is where the only weights that will ever matter are loaded; main_reconstruct.py:145-146 is the call this protects). Afterwards the word is still
     read (and cleared) but a calibrated context reports nothing more: the calibration itself tolerates `max_sat_fraction` of saturated values."""
 
-    def __init__(self, ctx, enabled=True, max_sat_fraction=1e-3):
-        self.ctx, self.enabled, self.max_sat_fraction = ctx, bool(enabled), float(max_sat_fraction)
+    def __init__(self, ctx, enabled=True, max_sat_fraction=1e-3, trigger_fraction=1e-2):
+        self.ctx, self.enabled, self.max_sat_fraction, self.trigger_fraction = ctx, bool(enabled), float(max_sat_fraction), float(trigger_fraction)
         self.calibrated, self.report, self.checks = False, None, 0
 
     def check(self, where="forward"):
@@ -50,14 +50,22 @@ class NumericsGuard(object):
                           "data-driven premultipliers - accuracy degrades towards plain fp16 for those values" % (where, ", ".join(names), self.ctx.precision),
                           RuntimeWarning, stacklevel=3)
             return None
+        # The warning word fires at the FIRST saturated value. Nets that roughly obey their BatchNorm statistics saturate a few per mille of
+        # merge_conv_a's outputs (measured: 0.1 .. 0.3 % on uncalibrated random nets, 0.22 % on the worst structured input - L_inf unchanged at 5e-5);
+        # the guard acts when more than `trigger_fraction` (1 %) of a plane's non-zero values saturate (x3.2 stress net: 5 %, L_inf 2e-4).
+        probe = self.ctx.calibrate(0, -1.0)
+        if max(probe["sat_act_before"], probe["sat_cat_before"], probe["sat_c4_before"]) < self.trigger_fraction:
+            self.calibrated = False              # nothing to redo, nothing to report - the watch goes on
+            return None
         cal = self.ctx.calibrate(0, self.max_sat_fraction)
         self.report = cal
         warnings.warn("surfacenet_amd (%s): stored activations of %s exceeded the range of their 6-bit code planes (%.2f %% of merge_conv_a's non-zero "
                       "outputs, %.2f %% of the concat buffer; the network's BatchNorm statistics under-estimate their spread). Premultipliers "
-                      "recalibrated on this batch: s_act %d -> %d, s_cat %d -> %d (saturated fraction now %.3f %% / %.3f %%); the batch is recomputed. "
-                      "Pass auto_calibrate=False to keep the static exponents."
+                      "recalibrated on this batch: s_act %d -> %d, s_cat %d -> %d, s_c4 %d -> %d (saturated fraction now %.3f %% / %.3f %% / %.3f %%); the "
+                      "batch is recomputed. Pass auto_calibrate=False to keep the static exponents."
                       % (where, ", ".join(names), 100 * cal["sat_act_before"], 100 * cal["sat_cat_before"], cal["s_act_before"], cal["s_act"],
-                         cal["s_cat_before"], cal["s_cat"], 100 * cal["sat_act"], 100 * cal["sat_cat"]), RuntimeWarning, stacklevel=3)
+                         cal["s_cat_before"], cal["s_cat"], cal["s_c4_before"], cal["s_c4"], 100 * cal["sat_act"], 100 * cal["sat_cat"], 100 * cal["sat_c4"]),
+                      RuntimeWarning, stacklevel=3)
         return cal
 
 

@@ -31,7 +31,11 @@ constexpr float kMxLoMul = (float)(1 << kMxLoExp);
 #ifndef SN_MX_S_CAT
 #define SN_MX_S_CAT 2
 #endif
+#ifndef SN_MX_S_C4
+#define SN_MX_S_C4 (-1)     // conv3_3's output and the conv4 chain (default mode, round 5): ReLU outputs with a heavier tail than merge_conv_a's - under s = 0 the
+#endif                      // saturated codes put the modelled L_inf at 1.5e-4 .. 2.8e-4, under s = -1 (range 15) at 9e-5 .. 1.1e-4 (oracle/net_emulation.py, tools/format_table.py)
 constexpr int kMxActE8 = SN_MX_FMT ? 127 - SN_MX_S_ACT : 127;
+constexpr int kMxC4E8 = SN_MX_FMT ? 127 - (SN_MX_S_C4) : 127;
 constexpr int kMxCatE8 = SN_MX_FMT ? 127 - SN_MX_S_CAT : 127;
 constexpr int kMxX0E8 = SN_MX_FMT ? 127 + 5 : 127;      // the network input (f16m8 mode only): mean-subtracted 8-bit colours, |x| < 256 -> 2^-5
 

@@ -426,9 +426,36 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     RUN((launch_conv<CONV3>(c, L["conv3_2"], a3, 160, b3, 160, 0, 160, nullptr, S, D3)));
     RUN((launch_conv<CONV3>(c, L["conv3_3"], b3, 160, a3, 160, 0, 160, nullptr, S, D3)));
     RUN((launch_conv<SIDE>(c, L["side_op3"], a3, 160, s3, 16, 0, 16, nullptr, S, D3)));
+    bool c4_done = false;
+    if constexpr (SP == 1 && SN_MX_FMT != 0) {
+        if (c->c4_m6) {
+            // Round 5: the dilated chain in the f16m8 arithmetic (the main term on the f16 MFMA, both correction terms on ONE 6-bit MX MFMA per 64 k: 1.5 MFMA
+            // units per product instead of 3), premultiplier 2^-1 (mx_c4_e8). conv3_3's output has two kinds of readers - side_op3 reads hi + lo planes,
+            // conv4_1 hi + code slots - so its code plane is derived from the stored planes by one small kernel; conv4_1 / conv4_2 store hi + codes,
+            // conv4_3 stores hi + lo again (side_op4 reads it in three-fp16-MFMA arithmetic).
+            {
+                const long long groups = (long long)S * (160 / 8) * D3 * D3 * D3;
+                const _Float16 lim = (_Float16)std::ldexp(SN_MX_FMT == 2 ? 7.5f : 28.f, c->mx_c4_e8 - 127);
+                unsigned short lim_bits; memcpy(&lim_bits, &lim, 2);
+                auto it = std::find(c->num_names.begin(), c->num_names.end(), std::string("conv3_3"));
+                const unsigned bit = it != c->num_names.end() ? (1u << (it - c->num_names.begin())) : 0u;
+                ProfScope ps(c, "conv3_3_codes", 0, (double)groups * 48.0);
+                hipLaunchKernelGGL(x3_to_m6_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, a3.p, a3.lo, reinterpret_cast<uint4 *>(c->a3c), groups,
+                                   c->mx_c4_e8, (unsigned)lim_bits, c->d_num, bit);
+                HIPCHK(hipGetLastError());
+            }
+            const Act a3m{a3.p, (long long)(c->a3c - a3.p)};
+            RUN((launch_conv<3, 2, 4, 5, EPI_STORE, 2, 1, 2, 8, 0>(c, L["conv4_1"], a3m, 160, a4, 304, 0, 304, nullptr, S, D3)));
+            RUN((launch_conv<3, 2, 4, 5, EPI_STORE, 2, 1, 2, 8, 0>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
+            RUN((launch_conv<3, 2, 4, 5, EPI_STORE, 2, 1, 2, 8, 0, 0, 1>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
+            c4_done = true;
+        }
+    }
+    if (!c4_done) {
     RUN((launch_conv<CONV4>(c, L["conv4_1"], a3, 160, a4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<CONV4>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<CONV4>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
+    }
     RUN((launch_conv<SIDE>(c, L["side_op4"], a4, 304, s4, 16, 0, 16, nullptr, S, D3)));
     if (cat_m8) { if constexpr (SP == 1) RUN((launch_up3<1, 2>(c, s2, s3, s4, cat, S, s, 64))); }
     else RUN((launch_up3<SP>(c, s2, s3, s4, cat, S, s, 64)));
@@ -550,6 +577,8 @@ static int ensure_workspace(sn_ctx *c)
     AL(s3, S * v3 * 16); AL(s4, S * v3 * 16);
     AL(ma, S * v1 * 104);
 #undef AL
+    if ((rc = dev_alloc(c, &c->a3c, (size_t)(S * v3 * 160))) != SN_OK) return rc;      // (one plane: the 16-byte code slots of conv3_3's output)
+    c->ws_owned.push_back(c->a3c);
     c->ws_ready = true; c->ws_split = c->split;
     return SN_OK;
 }
@@ -594,8 +623,9 @@ void sn_destroy(sn_ctx *c)
 // the static premultipliers of the 6-bit code planes (mx_format.h); sn_calibrate_dev replaces them with measured ones until the next call of this
 static void reset_mx_exponents(sn_ctx *c)
 {
-    c->mx_act_e8 = kMxActE8; c->mx_cat_e8 = kMxCatE8;
+    c->mx_act_e8 = kMxActE8; c->mx_cat_e8 = kMxCatE8; c->mx_c4_e8 = kMxC4E8;
     if (c->mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0) {                                    // accuracy sweeps only (mx_format.h)
+        if (sn_ab_switch("SN_MX_S_C4")) c->mx_c4_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_C4"))));
         if (sn_ab_switch("SN_MX_S_ACT")) c->mx_act_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_ACT"))));
         if (sn_ab_switch("SN_MX_S_CAT")) c->mx_cat_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_CAT"))));
     }
@@ -611,7 +641,12 @@ int sn_set_precision(sn_ctx *c, int mode)
     c->split = mode == SN_PRECISION_F16X3_PURE ? 1 : mode;
     c->tail_m8 = mode == SN_PRECISION_F16X3 ? 2 : 0;
     c->last_run_samples = 0;
+    // EXPERIMENT, off: measured -0.26 ms per step on the ping-pong loop (conv4_x 1.51 -> 1.26 ms) but the fp6 codes' static range fails on real pixels
+    // (dtu_real: L_inf 4.4e-4 on the device, 4.7e-4 in the model of the arithmetic; profiles/r5/format_table_*.json). Test-only twin: SN_C4_M6=1.
+    c->c4_m6 = false;
+    if (mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0 && sn_ab_switch("SN_C4_M6")) c->c4_m6 = atoi(sn_ab_switch("SN_C4_M6")) != 0;
     if (mode == SN_PRECISION_F16X3 && sn_ab_switch("SN_M8_TAIL")) c->tail_m8 = std::max(0, std::min(2, atoi(sn_ab_switch("SN_M8_TAIL"))));   // A/B measurements only
+    if (c->tail_m8 < 2) c->c4_m6 = false;
     reset_mx_exponents(c);
     return SN_OK;
 }
@@ -689,28 +724,38 @@ int sn_calibrate_dev(sn_ctx *c, int n_samples, double max_sat_fraction, sn_calib
     if (n_samples <= 0) n_samples = c->last_run_samples;
     if (n_samples > c->last_run_samples)
         return fail(SN_ERR_STATE, "sn_calibrate_dev: the last forward call ran %d samples, %d were asked for (the rest of the workspace holds older data)", c->last_run_samples, n_samples);
-    if (!(max_sat_fraction >= 0.0 && max_sat_fraction < 1.0)) return fail(SN_ERR_ARG, "sn_calibrate_dev: max_sat_fraction must be in [0, 1)");
+    const bool measure_only = max_sat_fraction < 0.0;      // report the saturated fractions under the exponents in force, change nothing
+    if (!measure_only && !(max_sat_fraction >= 0.0 && max_sat_fraction < 1.0)) return fail(SN_ERR_ARG, "sn_calibrate_dev: max_sat_fraction must be in [0, 1) (negative: measure only)");
     HIPCHK(hipSetDevice(c->device));
     const long long vox = (long long)c->s * c->s * c->s;
     const float lim = SN_MX_FMT == 2 ? 7.5f : 28.f;
+    // three code planes: 0 "act" = merge_conv_a's output, 1 "cat" = the concat buffer, 2 "c4" = conv3_3's output and the conv4 chain (what a forward call
+    // leaves of it: conv3_3's output, conv4_2's, conv4_3's - conv4_1's has been overwritten, it is the same kind of tensor)
+    constexpr int NT = 3, HB = kMxScanBins + 2;
     TmpDev tmp;
-    unsigned long long *d_hist = tmp.get<unsigned long long>(2 * (kMxScanBins + 2));
+    unsigned long long *d_hist = tmp.get<unsigned long long>(NT * HB);
     if (!d_hist) return fail(SN_ERR_HIP, "out of device memory");
-    HIPCHK(hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * 2 * (kMxScanBins + 2), c->stream));
-    const _Float16 *tens[2] = {c->ma, c->cat};
-    const long long halfs[2] = {(long long)n_samples * vox * 104, (long long)n_samples * vox * 64};
-    for (int t = 0; t < 2; ++t)
-        hipLaunchKernelGGL(mx_scan_kernel, dim3((unsigned)std::min<long long>(2048, (halfs[t] / 8 + 255) / 256)), dim3(256), 0, c->stream, tens[t], halfs[t], lim,
-                           d_hist + t * (kMxScanBins + 2));
+    HIPCHK(hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * NT * HB, c->stream));
+    struct Scan { const _Float16 *t; long long halfs; int slot; };
+    std::vector<Scan> scans = {{c->ma, (long long)n_samples * vox * 104, 0}, {c->cat, (long long)n_samples * vox * 64, 1}};
+    if (c->c4_m6) {
+        const long long v3 = vox / 64;
+        scans.push_back({c->a3, (long long)n_samples * v3 * 160, 2});
+        scans.push_back({c->b4, (long long)n_samples * v3 * 304, 2});
+        scans.push_back({c->a4, (long long)n_samples * v3 * 304, 2});
+    }
+    for (const Scan &sc : scans)
+        hipLaunchKernelGGL(mx_scan_kernel, dim3((unsigned)std::min<long long>(2048, (sc.halfs / 8 + 255) / 256)), dim3(256), 0, c->stream, sc.t, sc.halfs, lim,
+                           d_hist + sc.slot * HB);
     HIPCHK(hipGetLastError());
-    unsigned long long h[2][kMxScanBins + 2];
+    unsigned long long h[NT][HB];
     HIPCHK(hipMemcpyAsync(h, d_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    int s_new[2];
-    double sat_new[2], sat_old[2];
-    const int s_old[2] = {127 - c->mx_act_e8, 127 - c->mx_cat_e8};
-    for (int t = 0; t < 2; ++t) {
-        if (h[t][kMxScanBins] == 0) {      // an all-zero tensor says nothing about its range: the exponent stays
+    int s_new[NT];
+    double sat_new[NT], sat_old[NT];
+    const int s_old[NT] = {127 - c->mx_act_e8, 127 - c->mx_cat_e8, 127 - c->mx_c4_e8};
+    for (int t = 0; t < NT; ++t) {
+        if (h[t][kMxScanBins] == 0) {      // an all-zero (or unscanned) tensor says nothing about its range: the exponent stays
             s_new[t] = s_old[t]; sat_new[t] = sat_old[t] = 0.0;
             continue;
         }
@@ -719,13 +764,18 @@ int sn_calibrate_dev(sn_ctx *c, int n_samples, double max_sat_fraction, sn_calib
         int s = -kMxScanBins / 2;
         for (int cand = kMxScanBins / 2; cand >= -kMxScanBins / 2; --cand)
             if (frac(cand) <= max_sat_fraction) { s = cand; break; }
+        // (c4: three chained 300-channel layers accumulate what saturated codes lose - under the 1e-3 bound s = 0 may pass where the model of the arithmetic
+        // puts the optimum at the static s = -1 (tools/format_table.py) - so the calibration only ever WIDENS that plane's range beyond the static choice)
+        if (t == 2) s = std::min(s, SN_MX_S_C4);
+        if (measure_only) s = s_old[t];
         s_new[t] = s; sat_new[t] = frac(s); sat_old[t] = frac(std::max(-kMxScanBins / 2, std::min(kMxScanBins / 2, s_old[t])));
     }
     auto f16_of = [](unsigned long long bits) { unsigned short b = (unsigned short)bits; _Float16 v; memcpy(&v, &b, 2); return (float)v; };
     out->s_act_before = s_old[0]; out->s_cat_before = s_old[1]; out->s_act = s_new[0]; out->s_cat = s_new[1];
     out->sat_act_before = sat_old[0]; out->sat_cat_before = sat_old[1]; out->sat_act = sat_new[0]; out->sat_cat = sat_new[1];
     out->max_act = f16_of(h[0][kMxScanBins + 1]); out->max_cat = f16_of(h[1][kMxScanBins + 1]);
-    c->mx_act_e8 = 127 - s_new[0]; c->mx_cat_e8 = 127 - s_new[1];
+    out->s_c4_before = s_old[2]; out->s_c4 = s_new[2]; out->sat_c4_before = sat_old[2]; out->sat_c4 = sat_new[2]; out->max_c4 = f16_of(h[2][kMxScanBins + 1]);
+    c->mx_act_e8 = 127 - s_new[0]; c->mx_cat_e8 = 127 - s_new[1]; c->mx_c4_e8 = 127 - s_new[2];
     return SN_OK;
 }
 
@@ -816,7 +866,8 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
         }
         PackedConv L;
         L.name = sp.name; L.cin = sp.cin; L.cout = sp.cout; L.ks = k; L.dil = (sp.kind == K_DIL3) ? 2 : 1; L.act = sp.act;
-        const int lsplit = (c->split == 1 && ((c->tail_m8 >= 1 && L.name == "merge_conv_b") || (c->tail_m8 >= 2 && L.name == "merge_conv_a"))) ? 2 : c->split;   // see run_net_t
+        const int lsplit = (c->split == 1 && ((c->tail_m8 >= 1 && L.name == "merge_conv_b") || (c->tail_m8 >= 2 && L.name == "merge_conv_a") ||
+                                              (c->c4_m6 && sp.kind == K_DIL3))) ? 2 : c->split;   // see run_net_t
         const TileChoice tc = tile_for(sp, lsplit);
         std::vector<int> &oe = out_exps[sp.name];
         oe.assign(sp.cout, 0);

@@ -33,22 +33,30 @@ def tab(**kw):
 
 
 CANDIDATES = {
-    "shipped_r4 (merge m6)": ({}, {}),
+    "shipped (merge m6)": ({}, {}),
+    "conv4 m6 s=-1": (tab(m6=C4), {}),
+    "conv4 m6 s=0": (tab(m6=C4), {"s6_of": {"conv3_3": 0, "conv4_1": 0, "conv4_2": 0}}),
+    "conv4 m6 s=-2": (tab(m6=C4), {"s6_of": {"conv3_3": -2, "conv4_1": -2, "conv4_2": -2}}),
+    "conv4 m6 s=-1 + conv3 m6 s=0": (tab(m6=C4 + C3), {}),
+    "conv4 m6 s=-3": (tab(m6=C4), {"s6_of": {"conv3_3": -3, "conv4_1": -3, "conv4_2": -3}}),
+    "conv4 b6 s=0": (tab(b6=C4), {"s6_of": {"conv3_3": 0, "conv4_1": 0, "conv4_2": 0}}),
+    "conv4 b6 s=-1": (tab(b6=C4), {}),
+    "conv4 b6 s=-2": (tab(b6=C4), {"s6_of": {"conv3_3": -2, "conv4_1": -2, "conv4_2": -2}}),
+    "conv4 b6 s=-3": (tab(b6=C4), {"s6_of": {"conv3_3": -3, "conv4_1": -3, "conv4_2": -3}}),
     "conv4 m8": (tab(m8=C4), {}),
     "conv4 m8 s8=2": (tab(m8=C4), {"s8_act": 2}),
     "conv4_2,4_3 m8": (tab(m8=C4[1:]), {}),
-    "conv4 m6": (tab(m6=C4), {}),
     "conv4+conv3 m8": (tab(m8=C4 + C3), {}),
     "conv4+conv3+conv2 m8": (tab(m8=C4 + C3 + C2), {}),
     "conv4+conv3+conv2+conv1_2,1_3 m8": (tab(m8=C4 + C3 + C2 + C1[1:]), {}),
-    "merge m8 (rest x3)": (tab(m8=MG), {}),
+    "merge m8 (rest x3)": (tab(m8=MG, x3=C4), {}),
     "merge m8 + conv4 m8": (tab(m8=MG + C4), {}),
-    "all x3 (f16x3p)": (tab(x3=MG), {}),
+    "all x3 (f16x3p)": (tab(x3=MG + C4), {}),
 }
 MACS = {"conv1_1": 169869312, "conv1_2": 905969664, "conv1_3": 905969664, "conv2_1": 283115520, "conv2_2": 707788800, "conv2_3": 707788800,
         "conv3_1": 176947200, "conv3_2": 353894400, "conv3_3": 353894400, "conv4_1": 663552000, "conv4_2": 1244160000, "conv4_3": 1244160000,
         "merge_conv_a": 5662310400, "merge_conv_b": 8847360000}
-UNITS = {"x3": 3.0, "m8": 2.0, "m6": 1.5}
+UNITS = {"x3": 3.0, "m8": 2.0, "m6": 1.5, "b6": 1.5}
 
 
 def mfma_units(table):
@@ -65,6 +73,7 @@ def main():
     ap.add_argument("--seeds", default="32,33,34")
     ap.add_argument("--only", default="")
     ap.add_argument("--structured", action="store_true")
+    ap.add_argument("--real", action="store_true", help="the real DTU scan9 / Middlebury dino pixel windows of tests/golden/real_cases.npz (CVC by the C oracle)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import synth
@@ -72,7 +81,7 @@ def main():
     names = [n for n in CANDIDATES if not args.only or any(o in n for o in args.only.split(","))]
     rows = {n: {"units_per_product": round(mfma_units(CANDIDATES[n][0]), 4), "linf": {}} for n in names}
     cases = []
-    for seed in [int(x) for x in args.seeds.split(",")]:
+    for seed in [int(x) for x in args.seeds.split(",") if x]:
         values = list(synth.calibrated_params(seed % 3))
         X = synth.random_cvc(args.n_vp, args.s, seed + 10)
         cases.append(("noise seed %d" % seed, values, X))
@@ -81,6 +90,13 @@ def main():
         values = list(synth.calibrated_params(0))
         for label, X in tn._structured_inputs(args.s, 5).items():
             cases.append((label, values, X))
+    if args.real:
+        import golden_util
+        from oracle import cvc_oracle
+        values = list(synth.calibrated_params(1))
+        for name, c in golden_util.real_cases().items():
+            X = cvc_oracle.gen_coloredCubes(c["pairs"], c["xyz"], c["resol"], c["P"], golden_util.case_images(c), int(c["s"]), mean6=golden_util.MEAN6)
+            cases.append(("real pixels %s (s=%d)" % (name, int(c["s"])), values, X))
     for label, values, X in cases:
         t0 = time.time()
         _, u64 = net_oracle.forward_torch(X, values, n_vp=1)
