@@ -58,7 +58,7 @@ def _ilogb(a):
     return out
 
 
-def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act=S8_ACT, s6_of=None):
+def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act=S8_ACT, s6_of=None, m8_block_scale=True):
     import torch
     import torch.nn.functional as F
     assert mode in ("f16x3", "f16m8")
@@ -193,7 +193,10 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act
             Cp = (C + 7) // 8 * 8
             Wr = torch.cat([Wr, torch.zeros(O, Cp - C, Wr.shape[2], dtype=td)], dim=1)
             wh = f16(Wr)
-            whq, wlq = block_q(wh, (Wr - wh) * 2.0 ** le, kind, prod)
+            if prod == "m8" and not m8_block_scale:      # fp8 codes of the row-normalised weights as they are (e4m3 has the exponent range): no block scale
+                whq, wlq = q8(wh), q8((Wr - wh) * 2.0 ** le)
+            else:
+                whq, wlq = block_q(wh, (Wr - wh) * 2.0 ** le, kind, prod)
             wlq = wlq / 2.0 ** le
             # all three terms in renormalised units, then undo the row exponent (the input exponent is inside W')
             y = (cv(x.hi, wh) + cv(x.hi_q(prod), wlq) + cv(x.lo(prod), whq)) / torch.exp2(row.view(1, O, 1, 1, 1))

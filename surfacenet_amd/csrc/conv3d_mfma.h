@@ -45,108 +45,19 @@
 #include <stdint.h>
 #include <type_traits>
 
-// Compile-time ablation switches for profiling experiments (results are WRONG when != 0, except 2048): 1 halo staging only for
-// the first slab, 2 no per-piece barrier, 4 no MFMAs, 16 no weight-fragment reads, 32 no activation-fragment reads (2 .. 32: pipelined
-// loop only), 64 every weight piece = the layer's first (L2-resident), 128 / 256 parts of the pipelined loop's MX step, 512 store epilogues
-// store nothing, 1024 ... store every tile into tile 0's slots, 2048 ... issue every hi-plane store twice (results stay valid),
-// 4096 / 8192 (f16m8 ping-pong loop) every MFMA burst twice / half as long.
-#ifndef SN_ABL
-#define SN_ABL 0
-#endif
-// cache policy of the halo-tile LDS-DMA (aux bits of global_load_lds; 2 = nt: stream past L2 so the weight stream stays)
-#ifndef SN_HALO_AUX
-#define SN_HALO_AUX 0
-#endif
-#ifndef SN_XCD_REMAP
-#define SN_XCD_REMAP 1   // +0.7 % end to end (A/B, profiles/r1): neighbouring tiles share halos in one XCD's L2
-#endif
-#ifndef SN_STATIC_PRIO
-#define SN_STATIC_PRIO 1   // +0.7 % on the 3-D f16x3 / f16m8 kernels (merge_conv_b -1.6 %); -0.8 % in f16 mode and on the 2-D kernels -> off there
-#endif
-#ifndef SN_MX6_B128
-#define SN_MX6_B128 0     // 1: whole-slot ds_read_b128 (cheaper in the LDS: 4.6 vs 8.4 clocks per wave instruction, lds_probe) but 8 more live registers: merge_conv_b +0.5 %
-#endif
-#ifndef SN_DEFER
-#define SN_DEFER 2       // 1: f16m8 kernels only; 2: also conv2_x / conv3_x in f16x3 (-3..6 %; conv1_x +4 % and the 2-D nets +1.4 % -> not there; conv4_x spills)
-#endif
-#ifndef SN_DEFER_X3_GROUPS
-#define SN_DEFER_X3_GROUPS 2     // deferred groups of an f16x3 piece (1: conv2_x +4 %)
-#endif
-#ifndef SN_DEFER_X3_MAXACC
-#define SN_DEFER_X3_MAXACC 20
-#endif
-#ifndef SN_ESPREAD
-#define SN_ESPREAD 1
-#endif
-#ifndef SN_MX_B128
-#define SN_MX_B128 1     // f16m8 MX step: a lane covers BOTH correction terms of 2 channel groups (two 16-byte slot reads) instead of ONE term of 4 groups
-#endif                   // (four 8-byte reads): half the activation-fetch instructions of the step, 2 tap offsets instead of 4; the weight packing follows (pack_conv)
-// The two 8-voxel z-rows of a voxel fragment lie ROWGAP y-rows apart in the halo tile (1 = adjacent). Which LDS banks the four lane groups of
-// a ds_read_b128 X-fragment read hit depends on it; measured (PMC SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, r2v): gap 4 takes the 3x3x3
-// layers from 0.21-0.40 to 0.04-0.17 (conv2/3 0.31 -> 0.04, merge 0.23 -> 0.11, conv1 0.40 -> 0.17), +0.8 % end to end; it hurts the 1x1x1
-// side ops (0.28 -> 0.44), which keep gap 1.
-#ifndef SN_ROWGAP_3x3
-#define SN_ROWGAP_3x3 4
-#endif
-#ifndef SN_PMAP_GAP4
-#define SN_PMAP_GAP4 1
-#endif
-#ifndef SN_ROWGAP_2D
-#define SN_ROWGAP_2D 4   // 2-D nets (32 bytes per halo pixel, 10-pixel rows, two channel groups per pass): a fragment's rows 4 apart = 1,280 bytes = 256 mod 512:
-                         // the 32 lanes of an LDS pass then cover 512 distinct bytes (lds_probe: 37 vs 67 clocks per read under load)
-#endif
-#ifndef SN_ROWGAP_DIL2
-#define SN_ROWGAP_DIL2 2
-#endif
-#ifndef SN_WDIST
-#define SN_WDIST 2        // weight fragments are fetched from LDS this many MFMA groups ahead of their use (1 or 2). A wave that holds the SIMD's
-#endif                    // priority issues a group of 4 MFMAs in ~68 clocks, far less than a loaded ds_read_b128 takes: at distance 1 it stalls on
-                          // every group (wave_timing.py: the prioritised wave needs 3,900 clocks per piece for 1,930 clocks of MFMA issue)
-#ifndef SN_DMA_LATE
-#define SN_DMA_LATE 0     // issue the piece's DMAs behind its first MFMA group instead of in front of it: measured null (r2x: +-0.3 %, 30-step A/B)
-#endif
+// Fixed choices whose alternatives were measured and lost (A/B logs: profiles/r2 .. r4/README.md; the switches themselves were removed in round 5):
+// XCD-aware tile walk on; a fragment's two z-rows lie 4 y-rows apart in the halo tile of the 3x3x3 layers and of the 2-D nets (conflict-free LDS
+// passes: bank conflicts 0.21-0.40 -> 0.04-0.17, lds_probe), 2 apart under dilation 2, adjacent for the 1x1x1 side convolutions; the MX step's lane
+// covers BOTH correction terms of 2 channel groups (two 16-byte slot reads); ping-pong loops: branch-free weight-DMA issue, per-tile resync of the
+// two wave groups, the next slab's halo DMAs in the slab's first load slot, one K-chunk per segment.
+constexpr int kRowGap3x3 = 4, kRowGap2D = 4, kRowGapDil2 = 2;
 #ifndef SN_TIMING
-#define SN_TIMING 0       // diagnostic build: per-wave shader-clock totals (whole kernel + two columns) added into a.status[1..] (results stay valid). 1: {vmcnt wait,
-                          // barrier wait} per piece (pipelined loop) / {load, wait} per segment (ping-pong f16m8 loop); 2: {burst, wait}; 3..6: the same for the MX /
-                          // the f16 segments only; 7 / 8: sub-piece times of the pipelined loop; 9: the MX segments' vmcnt wait; 10: per TILE {epilogue, K loop}
-                          // (tools/wave_timing.py)
+#define SN_TIMING 0       // diagnostic build (tools/wave_timing.py): per-wave shader-clock totals added into a.status[2..] (results stay valid). One-wave-per-SIMD
+                          // loop: 1 {burst A, burst B}, 2 {vmcnt wait, barrier}, 3 {burst M, whole piece} per piece, 4 per slab {slab head, piece loop}; 10: per
+                          // TILE {epilogue, K loop} (every loop)
 #endif
-#ifndef SN_PP
-#define SN_PP 1           // 1: ping-pong K loop for the f16m8 3x3x3 kernels (merge_conv_a / merge_conv_b), see the slab loop
-#endif
-#ifndef SN_PPX
-#define SN_PPX 1          // 1: ping-pong K loop for the f16 / f16x3 3x3 kernels with at least two K-chunks per weight piece
-#endif
-#ifndef SN_PPX_MINNF
-#define SN_PPX_MINNF 1    // narrowest kernel (cout fragments per workgroup) that takes the ping-pong loop
-#endif
-#ifndef SN_PPX_HALO_SEG0
-#define SN_PPX_HALO_SEG0 1   // f16 / f16x3 ping-pong loop: the next slab's halo DMAs in the slab's FIRST load slot (behind the weight DMAs) instead of its second
-#endif
-#ifndef SN_PPX_SEGC
-#define SN_PPX_SEGC 1     // 2: two K-chunks per ping-pong segment where a chunk is a short burst (MF * NF <= 8: conv1_x)
-#endif
-#ifndef SN_PP_WIN
-#define SN_PP_WIN 1       // ping-pong: the next segment's weight fragments are read from inside the MFMA burst (see compute_f16); 1: EPI_FINAL kernels, 2: all
-#endif
-#ifndef SN_PP_WSPLIT
-#define SN_PP_WSPLIT 1    // SN_PP_WIN: weight DMA instalments issued with chunk 2p (the rest with chunk 2p+1, whose load segment is short)
-#endif
-#ifndef SN_PP_RESYNC
-#define SN_PP_RESYNC 1    // ping-pong: re-establish the group offset per tile so that both groups' epilogues overlap (see the tile loop)
-#endif
-#ifndef SN_PP_NOBR
-#define SN_PP_NOBR 2        // ping-pong loops: weight DMAs issued without per-item / per-piece branches (1: f16m8 loop, 2: f16 / f16x3 loop too): a wave
-                            // without an item of its own repeats the piece's last one. merge_conv_a -3..4 %, conv1_x -1.5 %, the rest unchanged (A/B r3w)
-#endif
-#ifndef SN_PW
-#define SN_PW 1           // 1: the f16m8 3x3x3 kernels launched as 4-wave workgroups (NW = 4, MF = 8) run the one-wave-per-SIMD K loop (round 4, see the slab loop)
-#endif
-// PWM loop: sched_barrier(0) behind every (MFMA, filler) pair pins the written order
+// one-wave-per-SIMD loop: sched_barrier(0) behind every (MFMA, filler) pair pins the written order
 #define PW_SB __builtin_amdgcn_sched_barrier(0)
-#ifndef SN_SETPRIO
-#define SN_SETPRIO 0     // s_setprio(1) around the MFMA groups: measured -0.5 % on this barrier-coupled structure
-#endif
 
 namespace sn {
 
@@ -186,8 +97,6 @@ struct ConvArgs {
     int act;              // 0 relu, 1 sigmoid
     int mx_in_e8, mx_out_e8, mx_side_e8;   // 6-bit MX forms (mx_format.h): E8M0 exponent 127 - s of the static premultiplier of the code planes
                                            // of the input tensor / of out and pool_out / of side_out
-    int stagger_clk;      // start delay (shader clocks) per phase step: workgroups start in 4 phases so that their
-                          // epilogue store bursts do not hit HBM at the same instant (0 = off)
     int nslab;
     int c8_last;          // 8-channel groups of the layer's LAST channel slab; every other slab holds the kernel's CS8 (pack_conv_host cuts them that way).
                           // (Round 4: the table of per-slab sizes this replaces lived in the kernel-argument segment, and "slab_c8[slab]" with a run-time
@@ -373,17 +282,17 @@ struct ConvCfg {
     static constexpr int KOFF_N = NTAP * CS8MAX + 24;      // + look-ahead padding (2 chunks; f16m8: one 8-group piece; bridged slabs: up to 7 units of the next slab)
     // one wave per SIMD (conv3d_f16_mfma, PWM loop): 4 waves x (8 voxel x NF cout) fragments, accumulators in AGPRs; the tap tables of ALL slabs
     // (x both halo buffers) are written once per launch instead of once per slab
-    static constexpr bool PWM = SN_PW && SPLIT == 2 && K2D == 0 && NW_ == 4 && KS == 3 && MF == 8 && SN_MX_FMT != 0 && PCH_ == 2;
+    static constexpr bool PWM = SPLIT == 2 && K2D == 0 && NW_ == 4 && KS == 3 && MF == 8 && SN_MX_FMT != 0 && PCH_ == 2;
     static constexpr int PW_SLABS = 16;                    // most channel slabs a PWM layer may have (launch_conv checks)
     // LDS distance of voxel fragment m from fragment 0 of the same lane under the row-gap-4 map (frag_xyz: hx = wave * XS + (m >> 2), hy = (m & 3) + 4 (v >> 3)):
     // a compile-time constant, so the PWM loop addresses all fragments as one per-lane register + the read's immediate offset
     static constexpr int pw_xoff(int m) { return (((m >> 2) * HY + (m & 3)) * HZ) * VS; }
     // the same under the row-gap-2 map (hy = (m & 1) + 4 ((m >> 1) & 1) + 2 (v >> 3)); XGAP = the map this kernel's 3-D form uses (frag_xyz)
-    static constexpr int XGAP = DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3;
+    static constexpr int XGAP = DIL == 2 ? kRowGapDil2 : kRowGap3x3;
     static constexpr int xoff_of(int m) { return XGAP == 4 ? pw_xoff(m) : (((m >> 2) * HY + (m & 1) + 4 * ((m >> 1) & 1)) * HZ) * VS; }
     // f16x3 3x3(x3) kernels on the ping-pong loop (PTAB): a slab's tap table depends only on the halo buffer it sits in, on its first unit (a function of
     // slab mod 4 with bridge chunks: 27 or 18 units per slab, 4 per chunk) and on whether it is the tile's last (b = 0, possibly fewer groups) - 8 tables per buffer, written once per launch instead of once per slab in a load slot
-    static constexpr bool PTAB = SN_PPX && SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && (K2D == 0 || SPLIT != 0) && !PWM;      // (= the kernels of the f16 / f16x3 ping-pong loop, 3-D and 2-D)
+    static constexpr bool PTAB = SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && (K2D == 0 || SPLIT != 0) && !PWM;      // (= the kernels of the f16 / f16x3 ping-pong loop, 3-D and 2-D)
     static constexpr int KTAB_N = PWM ? PW_SLABS * KOFF_N : (PTAB ? 8 * KOFF_N : KOFF_N);   // ints per halo buffer
     static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
     static constexpr int XPLANE = NSEG * 1024;
@@ -403,9 +312,9 @@ struct ConvCfg {
 template <int KS, int SPLIT, int NW, int PCH, int NF, int K2D, int MF = 4>
 constexpr bool sn_conv_has_bridge()
 {
-    return (SN_PPX && SN_PPX_SEGC == 1 && SPLIT == 1 && NW == 8 && KS == 3 && PCH >= 2 && NF >= SN_PPX_MINNF) ||
-           (SN_PP && SPLIT == 2 && K2D == 0 && NW == 8 && KS == 3 && SN_MX_FMT != 0) ||
-           (SN_PW && SPLIT == 2 && K2D == 0 && NW == 4 && MF == 8 && KS == 3 && PCH == 2 && SN_MX_FMT != 0);
+    return (SPLIT == 1 && NW == 8 && KS == 3 && PCH >= 2) ||
+           (SPLIT == 2 && K2D == 0 && NW == 8 && KS == 3 && SN_MX_FMT != 0) ||
+           (SPLIT == 2 && K2D == 0 && NW == 4 && MF == 8 && KS == 3 && PCH == 2 && SN_MX_FMT != 0);
 }
 
 // OSPLIT: storage format of the OUTPUT tensor (defaults to SPLIT): lets an f16x3 layer feed an f16m8 layer.
@@ -434,22 +343,11 @@ conv3d_f16_mfma(ConvArgs a)
     const size_t VOL = (size_t)DX * D * D;
     const int tstride = gridDim.x;
     auto slab_c8_of = [&](int sl) -> int { return sl + 1 == a.nslab ? a.c8_last : C::CS8MAX; };      // channel groups of slab sl (scalar arithmetic only)
-#if SN_XCD_REMAP
     // XCD-aware walk (speed only): workgroup i is observed to run on XCD i % 8; within each round of gridDim.x tiles XCD x
     // takes the contiguous run [x*G/8, (x+1)*G/8) so that neighbouring tiles (shared halos) meet in one L2.
     int tile = ((gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
-#else
-    int tile = blockIdx.x;
-#endif
     if (tile >= a.total_tiles) return;
 
-    if (a.stagger_clk > 0) {
-        // All workgroups do identical work per tile, so without this they stay in lockstep and write their output tiles
-        // in one chip-wide burst (measured: the store epilogue of merge_conv_a costs 18 % of the kernel that way).
-        const long long wait = (long long)((blockIdx.x >> 3) & 3) * a.stagger_clk;
-        const long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
     const char *const wsrc0 = reinterpret_cast<const char *>(a.wpack + (size_t)blockIdx.y * a.wsplit_stride);
 
     // ---- helpers ---------------------------------------------------------------------------------------------
@@ -483,7 +381,7 @@ conv3d_f16_mfma(ConvArgs a)
             const bool ok = part < c8n && hv < C::HVOX && (unsigned)gx < (unsigned)DX && (unsigned)gy < (unsigned)D &&
                             (unsigned)gz < (unsigned)D;
             const _Float16 *p = in_b + ((size_t)(c0 + part) * VOL + ((size_t)(gx * D + gy) * D + gz)) * 8 + (pl ? a.in_lo_off : 0);
-            dma16<SN_HALO_AUX>(ok ? (const void *)p : a.zero_page, xbuf + xb * C::XBUF + pl * C::XPLANE + seg * 1024);
+            dma16(ok ? (const void *)p : a.zero_page, xbuf + xb * C::XBUF + pl * C::XPLANE + seg * 1024);
             ++issued;
         }
         return issued;
@@ -502,8 +400,8 @@ conv3d_f16_mfma(ConvArgs a)
     // Preconditions (checked by launch_conv): only the first / last tile along an axis has out-of-volume halo voxels, and the
     // slab fits the offset field. The one-plane f16 mode of the 2-D nets (4-group slabs: up to 400 MB) keeps the generic path.
     constexpr bool BUFH = (K2D == 0) || (SPLIT != 0);
-    constexpr bool PPM = SN_PP && SPLIT == 2 && K2D == 0 && NW_ == 8 && KS == 3 && SN_MX_FMT != 0;   // ping-pong K loop, f16m8 kernels (slab loop)
-    constexpr bool PPX = SN_PPX && SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && BUFH && NF >= SN_PPX_MINNF;          // ... f16 / f16x3 kernels
+    constexpr bool PPM = SPLIT == 2 && K2D == 0 && NW_ == 8 && KS == 3 && SN_MX_FMT != 0;   // ping-pong K loop, f16m8 kernels (slab loop)
+    constexpr bool PPX = SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && BUFH;          // ... f16 / f16x3 kernels
     constexpr bool PP = PPM || PPX;
     constexpr bool PWM = C::PWM;                   // one wave per SIMD (slab loop)
     constexpr bool UNI = PP || PWM;                // loops in which hipcc's divergence analysis loses wave-uniform values (stage_halo_buf)
@@ -599,7 +497,7 @@ conv3d_f16_mfma(ConvArgs a)
     // The f16m8 kernels work in PIECES of 8 units (two f16 chunks + one MX step over the same 8): 27 units = 3.375 pieces were run as 4, the
     // 4th with one chunk, three units and a full-size weight DMA. Bridged, merge_conv_a's 8 slabs are 27 pieces instead of 32 and merge_conv_b's
     // 13 are 44 instead of 52; the bridge piece is a slab's third or fourth, behind the vmcnt(0) of the second piece's MX load slot.
-    constexpr bool BRIDGE_OK = (PPX && SPLIT == 1 && SN_PPX_SEGC == 1) || PPM || PWM;
+    constexpr bool BRIDGE_OK = (PPX && SPLIT == 1) || PPM || PWM;
     constexpr int UM = SPLIT == 2 ? 8 : 4;                   // units per chunk / per piece: what a slab's unit count is rounded up to
     constexpr int BSTEP = (UM - (C::NTAP * C::CS8MAX) % UM) % UM;      // bridged layers (all slabs hold CS8MAX groups): a slab starts this many units later (mod UM) than its predecessor
     const bool bridge = BRIDGE_OK && a.bridge != 0;
@@ -639,7 +537,7 @@ conv3d_f16_mfma(ConvArgs a)
     // LDS-DMA of `nch` K-chunks of packed weights starting at byte offset `off` of this split's stream
     auto stage_w = [&](size_t off, int nch, int wbi) {
         const int cnt = nch * NF * NPL;
-        const char *src = wsrc0 + ((SN_ABL & 64) ? 0 : off);   // ablation 64: always the same piece (L2-resident)
+        const char *src = wsrc0 + off;
         char *dst = wbuf + wbi * C::WBUF;
         for (int i = wave; i < cnt; i += C::NW) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
     };
@@ -648,15 +546,13 @@ conv3d_f16_mfma(ConvArgs a)
     // 2 y-rows x 8 z. PMAP (EPI_SIDEPOOL): wave w owns x in {2(w&3), 2(w&3)+1} x 4 y-rows, so that every 2x2x2 pooling cell lies inside ONE
     // wave (x partner = fragment m+2, y partner = lane^8, z partner = lane^1).
     constexpr bool PMAP = (EPI == EPI_SIDEPOOL);
-    static_assert(!PMAP || ((MF == 4 || (MF == 8 && SN_PMAP_GAP4)) && NW_ == 8 && K2D == 0), "EPI_SIDEPOOL: 8 waves x 4 (8) fragments over an 8x8x8 (16x8x8) tile");
+    static_assert(!PMAP || ((MF == 4 || MF == 8) && NW_ == 8 && K2D == 0), "EPI_SIDEPOOL: 8 waves x 4 (8) fragments over an 8x8x8 (16x8x8) tile");
     auto frag_xyz = [&](int m, int &hx, int &hy, int &hz) {
         if constexpr (C::F4) { hx = wave * MF + m; hy = v >> 2; hz = v & 3; }
-        else if constexpr (PMAP && SN_PMAP_GAP4) { hx = (MF / 2) * (wave & 3) + (m >> 1); hy = 2 * (wave >> 2) + (m & 1) + 4 * (v >> 3); hz = v & 7; }   // (MF = 8: four x-slices per wave)
-        else if constexpr (PMAP) { hx = 2 * (wave & 3) + (m >> 1); hy = 4 * (wave >> 2) + 2 * (m & 1) + (v >> 3); hz = v & 7; }
-        else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 4) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
-        else if constexpr (K2D == 0 && KS == 3 && (DIL == 2 ? SN_ROWGAP_DIL2 : SN_ROWGAP_3x3) == 2) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
-        else if constexpr (K2D == 1 && SN_ROWGAP_2D == 2 && C::VS == 32) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
-        else if constexpr (K2D == 1 && SN_ROWGAP_2D == 4 && C::VS == 32) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
+        else if constexpr (PMAP) { hx = (MF / 2) * (wave & 3) + (m >> 1); hy = 2 * (wave >> 2) + (m & 1) + 4 * (v >> 3); hz = v & 7; }   // (MF = 8: four x-slices per wave)
+        else if constexpr (K2D == 0 && KS == 3 && C::XGAP == 4) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
+        else if constexpr (K2D == 0 && KS == 3 && C::XGAP == 2) { hx = wave * C::XS + (m >> 2); hy = (m & 1) + 4 * ((m >> 1) & 1) + 2 * (v >> 3); hz = v & 7; }
+        else if constexpr (K2D == 1 && kRowGap2D == 4 && C::VS == 32) { hx = wave * C::XS + (m >> 2); hy = (m & 3) + 4 * (v >> 3); hz = v & 7; }
         else { hx = wave * C::XS + (m >> 2); hy = 2 * (m & 3) + (v >> 3); hz = v & 7; }
     };
     int xbase[MF];
@@ -708,17 +604,10 @@ conv3d_f16_mfma(ConvArgs a)
         stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         wg_barrier();
-        if constexpr (PP && !SN_PP_RESYNC) { if (wave >= C::NW / 2) wg_barrier(); }    // group 1 runs one barrier (= one segment slot) behind group 0
     }
-#if SN_STATIC_PRIO
-    // static priority for the younger half of an 8-wave workgroup (MI355X_MICROARCH.md, two waves per SIMD): waves 4-7 lose
-    // the VALU arbitration to waves 0-3 on every segment otherwise
-    // (r2z A/B with the deferred barrier: merge_conv_a/b -1.2 %, conv4_x 0, conv1_x / conv2_x +1..3 % -> only where a wave owns >= 7 cout fragments)
-    if (!PP && C::NW == 8 && SPLIT != 0 && K2D == 0 && (NF >= 7 || DIL == 2) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
     int xb = 0;     // halo / tap-table buffer holding the current slab
     int wbi = 0;    // weight buffer holding the current piece
-    long long t_vm = 0, t_bar = 0, n_piece = 0, t_mx = 0, t_rel = 0, t_c0 = 0, t_dma = 0;
+    long long t_vm = 0, t_bar = 0, n_piece = 0, t_rel = 0;      // SN_TIMING accumulators
     const long long t_kernel0 = SN_TIMING ? __builtin_readcyclecounter() : 0;
     bool bad = false;   // a stored value left the fp16 range / is NaN (checked on the fp32 value in the epilogue)
     f32x2_t trk_acc = {0.f, 0.f};   // ... the store epilogues' form of the same test (sn_track_acc / sn_track_h2)
@@ -748,11 +637,11 @@ conv3d_f16_mfma(ConvArgs a)
 
         int c0 = 0;
         size_t woff = 0;   // byte offset of the current slab in the weight stream
-        // SN_PP_RESYNC: the one-slot offset between the two wave groups is set up per TILE (group 1 waits one barrier here, group 0 one barrier
+        // The one-slot offset between the two wave groups is set up per TILE (group 1 waits one barrier here, group 0 one barrier
         // behind its last segment), so that both groups run the epilogue at the same time. With a free-running offset the tile boundary costs
         // two slots of (epilogue + load) each - a group's epilogue sits in its load slot while the partner's short MFMA burst ends and waits -
         // which merge_conv_a's store epilogue cannot afford (+4 % against the non-ping-pong kernel before this, A/B r3e).
-        if constexpr (PP && SN_PP_RESYNC) { if (wave >= C::NW / 2) wg_barrier(); }
+        if constexpr (PP) { if (wave >= C::NW / 2) wg_barrier(); }
         const long long t_tile0 = SN_TIMING == 10 ? __builtin_readcyclecounter() : 0;     // 10: per tile {epilogue, K loop}
         // PWM: what a piece hands to its successor - the operand fragments of the successor's first f16 chunk (read during the MX burst), the tap
         // offsets of its second chunk and of its MX step. A tile's first piece loads them cold, right here.
@@ -826,7 +715,7 @@ conv3d_f16_mfma(ConvArgs a)
                 // burst: by then every wave has read all it needs from the piece's weight buffer (so the piece after next may be fetched into
                 // it) and its share of the next piece's DMAs has landed (the MX burst reads the next piece's first fragments).
                 // Same K order, same MFMAs per accumulator as the ping-pong loop: bit-identical results.
-                static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_B128 && BUFH && DIL == 1 && SN_ROWGAP_3x3 == 4 && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0,
+                static_assert(SPLIT == 2 && C::PCH == 2 && BUFH && DIL == 1 && kRowGap3x3 == 4 && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0,
                               "one-wave-per-SIMD loop: f16m8 3x3x3 kernels");
                 long long pws1 = 0;                    // SN_TIMING 4: per slab {everything in front of the piece loop since the previous slab's last piece, the piece loop}
                 constexpr int mxo = 2 * NF * 1024;
@@ -1003,158 +892,111 @@ conv3d_f16_mfma(ConvArgs a)
             } else
             if constexpr (PPX) {
                 // ---- PING-PONG K loop, f16 / f16x3 kernels (round 3) ---------------------------------------------------
-                // Same structure as the f16m8 loop below: a segment = SEGC K-chunks; their NPLM * (MF + NF) operand fragments each are read into
-                // registers in the wave's LOAD slot (with the tap offsets of the next segment and the wave's DMA duties), their (SPLIT ? 3 : 1) * MF * NF
-                // MFMAs each run as one uninterrupted burst in its COMPUTE slot; wave group 1 runs one barrier behind group 0, so each SIMD's matrix
-                // pipe always belongs to exactly one wave. MFMA order per chunk = the software-pipelined loop's, so results are bit-identical to it.
-                // DMA duties: the next weight piece with the first segment of a piece, the next slab's halo tile with the second segment of a slab's
-                // first piece, the wait for the weights with the piece's last segment (the halo, younger, may stay in flight: counted wait).
-                // (tried, A/B r3j: the next slab's halo DMAs dealt out one or two per load segment instead of all HT in one - conv1_x +27 %,
-                // conv4_x +12 %, similarityNet -12 %: a load segment that carries any DMA pays for its set-up, and most of them are on the critical path)
-                static_assert(C::PCH >= 2 && BUFH && SPLIT != 2, "ping-pong loop (f16 / f16x3): at least two chunks per weight piece");
-                // SEGC = 2 where a chunk is a short burst (conv1_x: 24 MFMAs): halves the barriers per MFMA
-                constexpr int SEGC = (SN_PPX_SEGC == 2 && MF * NF <= 8 && C::PCH >= 3) ? 2 : 1;
-                constexpr int NSEGMAX = (C::PCH + SEGC - 1) / SEGC;
-                const unsigned koff_a = kbuf_a + (unsigned)((C::PTAB ? xb * 8 + (last_slab ? 4 : 0) + (slab & 3) : xb) * (C::KOFF_N * 4));
+                // Same structure as the f16m8 loop below: a segment = one K-chunk; its NPLM * (MF + NF) operand fragments are read into registers in
+                // the wave's LOAD slot (with the tap offset of the next segment and the wave's DMA duties), its (SPLIT ? 3 : 1) * MF * NF MFMAs run as
+                // one uninterrupted burst in its COMPUTE slot; wave group 1 runs one barrier behind group 0, so each SIMD's matrix pipe always belongs
+                // to exactly one wave. DMA duties: the next weight piece and (a slab's first piece) the next slab's halo tile with the first segment of
+                // a piece, the wait for the weights with the piece's last segment (the halo, younger, may stay in flight: counted wait).
+                // Measured and dropped (profiles/r3, r4 README): halo DMAs dealt out over the load slots or issued inside the burst, two chunks per
+                // segment, a scheduling barrier between operand reads and DMA duties.
+                static_assert(C::PCH >= 2 && BUFH && SPLIT != 2 && C::PTAB, "ping-pong loop (f16 / f16x3): at least two chunks per weight piece");
+                const unsigned koff_a = kbuf_a + (unsigned)((xb * 8 + (last_slab ? 4 : 0) + (slab & 3)) * (C::KOFF_N * 4));
                 const unsigned xslab = xbuf_a + xb * C::XBUF;
                 constexpr int NPLM = C::NPLM;
-                int ko[SEGC], ko_n[SEGC];
+                int ko, ko_n = 0;
                 const int bridge_b = su_b;                          // bridge chunks (write_koff_part): units this slab's last chunk takes from the next slab
-                // (tried, A/B r4am: a slab's first tap offset read in the previous slab's last load slot instead of by an LDS round trip at the head of the slab - no change)
-                static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_read32<j * 16>(ko[j], koff_a); ko_n[j] = 0; });
+                lds_read32<0>(ko, koff_a);
                 lgkm_wait<0>();
                 int p = 0;
                 do {
                     const int ch0 = p * C::PCH;
                     const unsigned wp = wbuf_a + wbi * C::WBUF;
-                    const int nch_p = (nchunk - ch0) < C::PCH ? (nchunk - ch0) : C::PCH;      // chunks of this piece (>= 1)
-                    const int nseg = (nch_p + SEGC - 1) / SEGC;                             // ... in segments
+                    const int nseg = (nchunk - ch0) < C::PCH ? (nchunk - ch0) : C::PCH;      // chunks (= segments) of this piece (>= 1)
                     int hnow = 0;
-                    static_for<0, NSEGMAX>([&](auto scc) {
+                    static_for<0, C::PCH>([&](auto scc) {
                         constexpr int sc = decltype(scc)::value;
                         if (sc < nseg) {
-                            // SN_TIMING 1 / 2 (diagnostic builds; this loop): per segment {load slot up to the barrier, wait at that barrier} / {MFMA burst, wait at the closing barrier}
-                            long long pxt[5] = {0, 0, 0, 0, 0};
-#define PX_T(i) do { if constexpr (SN_TIMING == 1 || SN_TIMING == 2 || SN_TIMING == 5) { pxt[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
-                            PX_T(0);
-                            half8 xf[SEGC][NPLM][MF], wf[SEGC][NPLM][NF];
-                            static_for<0, SEGC>([&](auto jc) {
-                                constexpr int j = decltype(jc)::value, cc = sc * SEGC + j;
-                                if (SEGC == 1 || cc < nch_p) {
-                                    const unsigned kos = xslab + (unsigned)ko[j];
-                                    // XIMM: under the row-gap maps of the 3-D kernels the distance of fragment m from fragment 0 is a compile-time constant
-                                    // (ConvCfg::xoff_of): one address register + immediate offsets instead of an add per read in the load slot
-                                    constexpr bool XIMM = K2D == 0 && !PMAP && KS == 3 && (C::XGAP == 4 || C::XGAP == 2) && C::XPLANE + C::xoff_of(MF - 1) < 65536;
-                                    const unsigned kos0 = (unsigned)xbase[0] + kos;
-                                    static_for<0, MF>([&](auto mc) {
-                                        constexpr int m = decltype(mc)::value;
-                                        if constexpr (XIMM) {
-                                            lds_read128<C::xoff_of(m)>(xf[j][0][m], kos0);
-                                            if constexpr (SPLIT == 1) lds_read128<C::XPLANE + C::xoff_of(m)>(xf[j][1][m], kos0);
-                                        } else {
-                                        lds_read128<0>(xf[j][0][m], (unsigned)xbase[m] + kos);
+                            half8 xf[NPLM][MF], wf[NPLM][NF];
+                            {
+                                const unsigned kos = xslab + (unsigned)ko;
+                                // XIMM: under the row-gap maps of the 3-D kernels the distance of fragment m from fragment 0 is a compile-time constant
+                                // (ConvCfg::xoff_of): one address register + immediate offsets instead of an add per read in the load slot
+                                constexpr bool XIMM = K2D == 0 && !PMAP && KS == 3 && C::XPLANE + C::xoff_of(MF - 1) < 65536;
+                                const unsigned kos0 = (unsigned)xbase[0] + kos;
+                                static_for<0, MF>([&](auto mc) {
+                                    constexpr int m = decltype(mc)::value;
+                                    if constexpr (XIMM) {
+                                        lds_read128<C::xoff_of(m)>(xf[0][m], kos0);
+                                        if constexpr (SPLIT == 1) lds_read128<C::XPLANE + C::xoff_of(m)>(xf[1][m], kos0);
+                                    } else {
+                                        lds_read128<0>(xf[0][m], (unsigned)xbase[m] + kos);
                                         if constexpr (SPLIT == 1) {
-                                            if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(xf[j][1][m], (unsigned)xbase[m] + kos);
-                                            else lds_read128<0>(xf[j][1][m], (unsigned)xbase[m] + kos + C::XPLANE);
+                                            if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(xf[1][m], (unsigned)xbase[m] + kos);
+                                            else lds_read128<0>(xf[1][m], (unsigned)xbase[m] + kos + C::XPLANE);
                                         }
-                                        }
-                                    });
-                                    static_for<0, NF>([&](auto nc) {
-                                        constexpr int n = decltype(nc)::value;
-                                        lds_read128<(cc * NF + n) * C::MFRAG>(wf[j][0][n], wp);
-                                        if constexpr (SPLIT == 1 && !(SN_ABL & 16384)) lds_read128<(cc * NF + n) * C::MFRAG + 1024>(wf[j][1][n], wp);      // (ablation 16384: no lo-plane weight reads - wrong results, LDS traffic -25 %)
-                                        if constexpr (SPLIT == 1 && (SN_ABL & 16384)) wf[j][1][n] = wf[j][0][n];
-                                    });
-                                }
-                                lds_read32<0>(ko_n[j], koff_a + (unsigned)(ch0 + (sc + 1) * SEGC + j) * 16);      // tap offsets of the next segment's chunks
-                            });
-                            // (tried, A/B r4aa: a scheduling barrier here, so that the DMA duties and their ~35 scalar instructions go out behind the operand reads - no
-                            // change anywhere: the load slot is bounded by the LDS itself, 4 loading waves x 16 KiB per 768-clock burst of the partner group)
+                                    }
+                                });
+                                static_for<0, NF>([&](auto nc) {
+                                    constexpr int n = decltype(nc)::value;
+                                    lds_read128<(sc * NF + n) * C::MFRAG>(wf[0][n], wp);
+                                    if constexpr (SPLIT == 1) lds_read128<(sc * NF + n) * C::MFRAG + 1024>(wf[1][n], wp);
+                                });
+                                lds_read32<0>(ko_n, koff_a + (unsigned)(ch0 + sc + 1) * 16);      // tap offset of the next segment's chunk
+                            }
                             if constexpr (sc == 0) {
-                                // the piece after this one: next piece of the slab (possibly short), else the first piece of the next slab / tile
-                                const bool w_next = (p + 1 < npiece) || have_next;
+                                // the piece after this one: next piece of the slab (possibly short), else the first piece of the next slab / tile.
+                                // Branch-free issue: always the compile-time maximum per wave; an index beyond the piece repeats its last item (same
+                                // bytes, same place), and behind the layer's last piece its first one is fetched into the idle buffer
+                                const bool real = (p + 1 < npiece) || have_next;
                                 const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : nwoff;
                                 int w_nch = C::PCH;
                                 if (p + 1 < npiece) { const int rem = wchunk - (ch0 + C::PCH); if (rem < C::PCH) w_nch = rem; }
                                 else { if (n_wchunk < C::PCH) w_nch = n_wchunk; }
-                                if constexpr (SN_PP_NOBR >= 2) {
-                                    // branch-free issue: always the compile-time maximum per wave; an index beyond the piece repeats its last item (same
-                                    // bytes, same place), and behind the layer's last piece its first one is fetched into the idle buffer
-                                    const bool real = w_next;
-                                    const char *src = wsrc0 + (real ? w_off : 0);
-                                    char *dst = wbuf + (wbi ^ 1) * C::WBUF;
-                                    const int nch0 = wchunk0;
-                                    const int cnt = (real ? w_nch : (nch0 < C::PCH ? nch0 : C::PCH)) * NF * NPL;
-                                    constexpr int WPWX = (C::PCH * NF * NPL + C::NW - 1) / C::NW;
-                                    static_for<0, WPWX>([&](auto kc) {
-                                        int i = decltype(kc)::value * C::NW + wave;
-                                        i = i < cnt ? i : cnt - 1;
-                                        dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
-                                    });
-                                } else
-                                if (w_next) {
-                                    const char *src = wsrc0 + w_off;
-                                    char *dst = wbuf + (wbi ^ 1) * C::WBUF;
-                                    const int cnt = w_nch * NF * NPL;
-                                    for (int i = wave; i < cnt; i += C::NW) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
-                                }
-                                if constexpr (!C::PTAB) { if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, nslab_i, tid, C::NT / 2); }
+                                const char *src = wsrc0 + (real ? w_off : 0);
+                                char *dst = wbuf + (wbi ^ 1) * C::WBUF;
+                                const int cnt = (real ? w_nch : (wchunk0 < C::PCH ? wchunk0 : C::PCH)) * NF * NPL;
+                                constexpr int WPWX = (C::PCH * NF * NPL + C::NW - 1) / C::NW;
+                                static_for<0, WPWX>([&](auto kc) {
+                                    int i = decltype(kc)::value * C::NW + wave;
+                                    i = i < cnt ? i : cnt - 1;
+                                    dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
+                                });
+                                // the next slab's halo tile, behind the weight DMAs
+                                if (p == 0 && have_next)
+                                    hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
                             }
-                            // the next slab's halo tile: second segment of the slab's first piece (first segment if the piece has only one)
-                            // (tried, A/B r4ae / r4af, profiles/r4/hib_experiment.patch: these DMAs inside the MFMA burst of the slab's first segment instead, one behind every few
-                            // MFMAs - conv1_x / s_conv1_2 -3 %, conv2_x .. conv4_x +3..8 %, similarityNet -2 %: a DMA that waits for the texture path stalls the burst itself)
-                            long long pxh0 = 0, pxh1 = 0, pxh2 = 0;       // SN_TIMING 6: per segment {the vmcnt wait of the load slot, the halo DMA issue}
-                            if constexpr (SN_TIMING == 6) { pxh0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-                            if (p == 0 && have_next && !(SN_ABL & 1) && sc == ((nseg >= 2 && !SN_PPX_HALO_SEG0) ? 1 : 0))
-                                hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
-                            if constexpr (SN_TIMING == 6) { pxh1 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                             // (bridge chunk next: it reads the NEXT slab's halo tile - everything this wave has in flight must have landed before the barrier)
                             const bool pre_bridge = bridge_b > 0 && ch0 + sc == nchunk - 2;
                             if (sc == nseg - 1) {
-                                // the next weight piece has landed; halo DMAs issued in THIS load segment may still fly unless the slab ends here
-                                if (!pre_bridge && p + 1 < npiece && (sc == 1 || SN_PPX_HALO_SEG0) && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
-                                else if (!pre_bridge && p + 1 < npiece && (sc == 1 || SN_PPX_HALO_SEG0) && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
+                                // the next weight piece has landed; halo DMAs issued in this piece's first load segment may still fly unless the slab ends here
+                                if (!pre_bridge && p + 1 < npiece && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
+                                else if (!pre_bridge && p + 1 < npiece && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
                                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             } else if (pre_bridge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            if constexpr (SN_TIMING == 6) { pxh2 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_vm += pxh2 - pxh1; t_bar += pxh1 - pxh0; ++n_piece; }
                             lgkm_wait<0>();
-                            static_for<0, SEGC>([&](auto jc) { constexpr int j = decltype(jc)::value; ko[j] = ko_n[j]; });
-                            PX_T(1);
+                            ko = ko_n;
                             wg_barrier();
-                            PX_T(2);
                             __builtin_amdgcn_sched_barrier(0);
-                            static_for<0, SEGC * ((SN_ABL & 4096) ? 2 : 1)>([&](auto jc) {       // (ablation 4096: every burst issued twice - what would a segment of twice the length buy?)
-                                constexpr int j = decltype(jc)::value % SEGC, cc = sc * SEGC + j;
-                                if (SEGC == 1 || cc < nch_p) {
 #pragma unroll
-                                    for (int n = 0; n < NF; ++n) {
-                                        if constexpr (SPLIT == 1) {
+                            for (int n = 0; n < NF; ++n) {
+                                if constexpr (SPLIT == 1) {
 #pragma unroll
-                                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][1][n], xf[j][0][m], acc[m][n], 0, 0, 0);
+                                    for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][n], xf[0][m], acc[m][n], 0, 0, 0);
 #pragma unroll
-                                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][0][n], xf[j][1][m], acc[m][n], 0, 0, 0);
-                                        }
-#pragma unroll
-                                        for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][0][n], xf[j][0][m], acc[m][n], 0, 0, 0);
-                                    }
+                                    for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][n], xf[1][m], acc[m][n], 0, 0, 0);
                                 }
-                            });
+#pragma unroll
+                                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][n], xf[0][m], acc[m][n], 0, 0, 0);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
-                            PX_T(3);
                             wg_barrier();
-                            PX_T(4);
-#undef PX_T
-                            if constexpr (SN_TIMING == 1) { t_vm += pxt[1] - pxt[0]; t_bar += pxt[2] - pxt[1]; ++n_piece; }
-                            if constexpr (SN_TIMING == 2) { t_vm += pxt[3] - pxt[2]; t_bar += pxt[4] - pxt[3]; ++n_piece; }
-                            if constexpr (SN_TIMING == 5) { if (t_rel != 0) { t_vm += pxt[0] - t_rel; if (sc == 0) t_bar += pxt[0] - t_rel; } t_rel = pxt[4]; ++n_piece; }      // 5: {gap between segments, of which in front of a piece's first}
                         }
                     });
                     wbi ^= 1;
                 } while (++p < npiece);
-                if constexpr (SN_TIMING == 5) { if (last_slab) t_rel = 0; }
             } else
             if constexpr (PPM) {
-                // ---- PING-PONG K loop (round 3) ------------------------------------------------------------------
+                // ---- PING-PONG K loop, f16m8 kernels launched as eight-wave workgroups (round 3; since round 4 only the all-MX mode's 3x3x3 layers) --
                 // The two waves of a SIMD (wave w of group 0 = waves 0..3 and wave w + 4 of group 1) never compete for the matrix pipe: a
                 // SEGMENT (one K-chunk of f16 MFMAs, or one MX step) is LOADED - every operand fragment of the segment read from LDS into
                 // registers, plus this wave's share of the DMA issue - and then COMPUTED as one uninterrupted burst of MF*NF MFMAs whose operands are
@@ -1163,12 +1005,10 @@ conv3d_f16_mfma(ConvArgs a)
                 // address arithmetic, the DMA issue, the register shuffles of the 6-bit operands all sit in the load segment. Buffer recycling
                 // needs no barrier of its own: the last reader of a weight piece / halo buffer (group 1, loading the piece's last segment) has
                 // waited for its reads before the barrier that precedes the first load slot of the next piece, where the refill DMAs are issued.
-                // Measured and dropped again (DESIGN.md sections 4.2 / 8; the code is in the history of this file): one designated DMA wave per slot,
-                // halo DMAs spread over the pieces, the closing barrier in front of the burst's last MFMAs, both f16 chunks loaded in one slot,
-                // MX weights read with the f16 chunks' loads, 96-bit reads of the code slots, a two-segment piece (both f16 chunks in one burst).
-                static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_FMT != 0 && SN_MX_B128 && BUFH, "ping-pong loop: f16m8 kernels with 6-bit MX operands");
-                // in-burst weight prefetch: merge_conv_b -2..3 %; merge_conv_a +15 % while its epilogue spilled, +0.5 % since (A/B r3e-r3i, r3w) -> EPI_FINAL kernels only
-                constexpr int PPWIN = (SN_PP_WIN == 2 || (SN_PP_WIN == 1 && EPI == EPI_FINAL)) ? 1 : 0;
+                // Measured and dropped again (DESIGN.md sections 4.2 / 8; profiles/r3/README.md): one designated DMA wave per slot, halo DMAs spread
+                // over the pieces, the closing barrier in front of the burst's last MFMAs, both f16 chunks loaded in one slot, MX weights read with the
+                // f16 chunks' loads, 96-bit reads of the code slots, the next segment's weight fragments requested from inside the burst.
+                static_assert(SPLIT == 2 && C::PCH == 2 && SN_MX_FMT != 0 && BUFH, "ping-pong loop: f16m8 kernels with 6-bit MX operands");
                 const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
                 const unsigned k2_a = koff_a + kq * 4;
                 const unsigned xslab = xbuf_a + xb * C::XBUF;       // (wave-uniform; the per-lane fragment offsets xbase[] stay the only address registers)
@@ -1180,43 +1020,26 @@ conv3d_f16_mfma(ConvArgs a)
                 lgkm_wait<0>();
                 constexpr int WCNT = C::PCH * NF * NPL;                     // 1 KiB DMAs per weight piece
                 constexpr int WPW = (WCNT + C::NW - 1) / C::NW;             // ... per wave
-                // items [k0, k1) of this wave's share of the piece at byte offset `off` of the weight stream, into weight buffer wb
+                // items [k0, k1) of this wave's share of the piece at byte offset `off` of the weight stream, into weight buffer wb (branch-free: a wave
+                // without an item of its own repeats the piece's last one - same bytes, same place)
                 auto stage_w_part = [&](size_t off, int wb, int k0, int k1) {
                     const char *src = wsrc0 + off;
                     char *dst = wbuf + wb * C::WBUF;
                     for (int k = k0; k < k1; ++k) {
                         int i = k * C::NW + wave;
-                        if constexpr (SN_PP_NOBR) {            // branch-free: a wave without an item of its own repeats the piece's last one (same bytes, same place)
-                            i = i < WCNT ? i : WCNT - 1;
-                            dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
-                        } else
-                        if (i < WCNT) dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
+                        i = i < WCNT ? i : WCNT - 1;
+                        dma16(src + (size_t)i * 1024 + lane * 16, dst + i * 1024);
                     }
                 };
                 int p = 0;
                 do {             // (do-while: a possible zero-trip path made hipcc spill 88 accumulator registers around the loop)
                     const int ch0 = p * C::PCH;
                     const unsigned wp = wbuf_a + wbi * C::WBUF;
-                    // the piece after this one: next piece of the slab, else the first piece of the next slab / tile
-                    const bool w_next = SN_PP_NOBR ? true : ((p + 1 < npiece) || have_next);      // (NOBR: behind the last piece of all, piece 0 of the layer is fetched into the idle buffer)
-                    const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : (SN_PP_NOBR && !have_next ? 0 : nwoff);
+                    // the piece after this one: next piece of the slab, else the first piece of the next slab / tile (behind the last piece of all, piece 0
+                    // of the layer is fetched into the idle buffer)
+                    const size_t w_off = (p + 1 < npiece) ? woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG : (!have_next ? 0 : nwoff);
                     const bool has_B = ch0 + 1 < nchunk;             // (the last piece of a slab with an odd chunk count has no second f16 chunk)
                     int hnow = 0;
-                    // SN_TIMING (diagnostic builds): shader-clock stamps 0 segment start | 1 operands landed | 2 barrier released | 3 MFMAs issued | 4 barrier released;
-                    // odd values accumulate {load 0-1, wait 1-2}, even {compute 2-3, wait 3-4}; 1/2 all segments, 3/4 MX segments only, 5/6 f16 segments only.
-                    // (a stamp's lgkmcnt(0) also waits for the wave's in-flight prefetch reads: the "load" figure of a segment that follows an in-burst
-                    // prefetch contains their tail - that is how an LDS-DMA instruction once seemed to cost 140-190 clocks; dma_probe: 19-47)
-                    long long ppt[5] = {0, 0, 0, 0, 0};
-#define PP_T(i) do { if constexpr (SN_TIMING) { ppt[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
-                    auto pp_account = [&](bool mx) {
-                        if constexpr (SN_TIMING >= 1 && SN_TIMING <= 6) {
-                            if ((SN_TIMING <= 2) || ((SN_TIMING <= 4) == mx)) {
-                                if (SN_TIMING & 1) { t_vm += ppt[1] - ppt[0]; t_bar += ppt[2] - ppt[1]; }
-                                else { t_vm += ppt[3] - ppt[2]; t_bar += ppt[4] - ppt[3]; }
-                                ++n_piece;
-                            }
-                        }
-                    };
                     half8 xf[2][MF], wf[2][NF];                     // operands of the f16 chunks 2p, 2p+1
                     constexpr int mxo = 2 * NF * 1024;
                     v4i wa4[NF];                                    // MX step: a lane's 192-bit weight operand = 128 + 64 bits ...
@@ -1224,88 +1047,46 @@ conv3d_f16_mfma(ConvArgs a)
                     typedef int v2i_ __attribute__((ext_vector_type(2)));
                     using I0 = std::integral_constant<int, 0>;
                     using I1 = std::integral_constant<int, 1>;
-                    using I2 = std::integral_constant<int, 2>;
-                    auto load_x = [&](auto ccc, int ko) {             // the activation fragments of f16 chunk cc
+                    auto load_f16 = [&](auto ccc, int ko) {           // the activation and weight fragments of f16 chunk cc
                         constexpr int cc = decltype(ccc)::value;
                         const unsigned kos = xslab + (unsigned)ko;
                         static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<0>(xf[cc][m], (unsigned)xbase[m] + kos); });
-                    };
-                    auto load_f16 = [&](auto ccc, int ko) {           // ... and its weight fragments
-                        constexpr int cc = decltype(ccc)::value;
-                        load_x(ccc, ko);
                         static_for<0, NF>([&](auto nc) { constexpr int n = decltype(nc)::value; lds_read128<(cc * NF + n) * 1024>(wf[cc][n], wp); });
                     };
-                    auto load_mxw = [&]() {                           // the MX weight fragments and their scales
-                        lds_read64<mxo + 1024 + 8>(wsc, wp);
-                        static_for<0, NF>([&](auto nc) {
-                            constexpr int n = decltype(nc)::value;
-                            lds_read128i<mxo + n * 2048>(wa4[n], wp);
-                            lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
-                        });
-                    };
-                    // PPWIN: the NEXT segment's weight fragments are requested from inside this burst, one fragment behind every group of MF MFMAs
-                    // (pre: 0 none | 1 the f16 fragments of chunk 2p+1 | 2 the MX step's): an LDS read costs a loading wave 25-40 clocks of its load
-                    // slot (dma_probe), a computing wave ~10 of its burst. The reads land during the wave's next load segment, whose lgkmcnt(0) covers them.
-                    auto compute_f16 = [&](auto ccc, auto prec) {
-                        constexpr int cc = decltype(ccc)::value, pre = decltype(prec)::value;
+                    auto compute_f16 = [&](auto ccc) {
+                        constexpr int cc = decltype(ccc)::value;
                         static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
 #pragma unroll
-                            for (int m = 0; m < ((SN_ABL & 8192) ? MF / 2 : MF); ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);   // (ablation 8192: half bursts)
-                            if constexpr (SN_ABL & 4096) {        // ablation 4096: every burst twice as long (is a slot bounded by the burst or by the partner's load?)
-#pragma unroll
-                                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);
-                            }
-                            if constexpr (pre == 1) { lds_read128<(NF + n) * 1024>(wf[1][n], wp); __builtin_amdgcn_sched_barrier(0); }
-                            if constexpr (pre == 2) {
-                                if constexpr (n == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
-                                lds_read128i<mxo + n * 2048>(wa4[n], wp);
-                                lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
+                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][n], xf[cc][m], acc[m][n], 0, 0, 0);
                         });
                     };
-                    constexpr int WSPLIT = PPWIN ? SN_PP_WSPLIT : (WPW + 1) / 2;    // weight DMA instalments [0, WSPLIT) with chunk 2p, [WSPLIT, WPW) with chunk 2p+1
+                    constexpr int WSPLIT = (WPW + 1) / 2;    // weight DMA instalments [0, WSPLIT) with chunk 2p, [WSPLIT, WPW) with chunk 2p+1
                     // ---- segment A: f16 chunk 2p; DMA: first part of the next weight piece; group 0 also writes the next slab's tap table
-                    PP_T(0);
                     load_f16(I0{}, koA);
-                    if (w_next) stage_w_part(w_off, wbi ^ 1, 0, WSPLIT);
+                    stage_w_part(w_off, wbi ^ 1, 0, WSPLIT);
                     if (p == 0 && have_next && wave < C::NW / 2) write_koff_part(nc8n, xb ^ 1, nslab_i, tid, C::NT / 2);
                     lgkm_wait<0>();
-                    PP_T(1);
                     wg_barrier();
-                    PP_T(2);
                     __builtin_amdgcn_sched_barrier(0);
-                    // (chunk 2p+1's fragments are requested even when the piece has no such chunk - in-bounds reads of the zero padding, never
-                    // used: a burst per case doubled the kernel's register pressure)
-                    if constexpr (PPWIN) compute_f16(I0{}, I1{}); else compute_f16(I0{}, I0{});
+                    compute_f16(I0{});
                     __builtin_amdgcn_sched_barrier(0);
-                    PP_T(3);
                     wg_barrier();
-                    PP_T(4);
-                    pp_account(false);
                     // ---- segment B: f16 chunk 2p+1; DMA: the rest of the next weight piece
                     if (has_B) {
-                        PP_T(0);
-                        if constexpr (PPWIN) load_x(I1{}, koB); else load_f16(I1{}, koB);
-                        if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW);
+                        load_f16(I1{}, koB);
+                        stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW);
                         lgkm_wait<0>();
-                        PP_T(1);
                         wg_barrier();
-                        PP_T(2);
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (PPWIN) compute_f16(I1{}, I2{}); else compute_f16(I1{}, I0{});
+                        compute_f16(I1{});
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_T(3);
                         wg_barrier();
-                        PP_T(4);
-                        pp_account(false);
                     } else {
-                        if (w_next) stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW);
+                        stage_w_part(w_off, wbi ^ 1, WSPLIT, WPW);
                     }
                     // ---- segment M: the MX step of the piece's 64 k; DMA: the next slab's halo tile (first piece of a slab); waits for the weights
                     {
-                        PP_T(0);
                         v4i x8h[MF][2];                                       // whole code slots (4 LDS cycles per read instead of 8 for 96 bits; the pad dword is dropped below)
                         int koAn = 0, koBn = 0;
                         long long k2n = 0;
@@ -1315,25 +1096,23 @@ conv3d_f16_mfma(ConvArgs a)
                             lds_read128i<0>(x8h[m][0], (unsigned)xbase[m] + ks0);
                             lds_read128i<0>(x8h[m][1], (unsigned)xbase[m] + ks1);
                         });
-                        if (!(PPWIN && has_B)) load_mxw();                     // (else: requested from inside chunk 2p+1's burst)
+                        lds_read64<mxo + 1024 + 8>(wsc, wp);                  // the MX weight fragments and their scales
+                        static_for<0, NF>([&](auto nc) {
+                            constexpr int n = decltype(nc)::value;
+                            lds_read128i<mxo + n * 2048>(wa4[n], wp);
+                            lds_read64<mxo + n * 2048 + 1024>(wb2[n], wp);
+                        });
                         if (p + 1 < npiece) {
                             lds_read32<0>(koAn, koff_a + (unsigned)(ch0 + 2) * 16);
                             lds_read32<0>(koBn, koff_a + (unsigned)(ch0 + 3) * 16);
                             lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
                         }
-                        if (p == 0 && have_next && !(SN_ABL & 1))
+                        if (p == 0 && have_next)
                             hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
-                        long long pptv = 0;
-                        if constexpr (SN_TIMING == 9) { lgkm_wait<0>(); pptv = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                         // the next weight piece (issued two load slots ago) has landed; this slab's halo DMAs, just issued, may still fly
                         if (p + 1 < npiece && hnow == HT) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT) : "memory");
                         else if (p + 1 < npiece && HT > 1 && hnow == HT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HT > 1 ? HT - 1 : 0) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if constexpr (SN_TIMING == 9) {      // 9: MX segments {the vmcnt wait alone, everything in front of it}
-                            const long long tq = __builtin_readcyclecounter();
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            t_vm += tq - pptv; t_bar += pptv - ppt[0]; ++n_piece;
-                        }
                         lgkm_wait<0>();
                         v8i x8[MF], wa[NF];
 #pragma unroll
@@ -1353,57 +1132,38 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                         for (int m = 0; m < MF; ++m) asm volatile("" : "+v"(x8[m]));
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_T(1);
                         wg_barrier();
-                        PP_T(2);
                         __builtin_amdgcn_sched_barrier(0);
                         static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
                             const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
 #pragma unroll
-                            for (int m = 0; m < ((SN_ABL & 8192) ? MF / 2 : MF); ++m)
+                            for (int m = 0; m < MF; ++m)
                                 acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
-                            if constexpr (SN_ABL & 4096) {
-#pragma unroll
-                                for (int m = 0; m < MF; ++m)
-                                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[n], x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
-                            }
                         });
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_T(3);
                         wg_barrier();
-                        PP_T(4);
-                        pp_account(true);
                     }
-#undef PP_T
                     wbi ^= 1;
                 } while (++p < npiece);
             } else {
-            // ---- software-pipelined K loop over this slab ----------------------------------------------------
-            // Register stages: X fragments of chunk c+1 and the tap offset of chunk c+2 are fetched while chunk c
-            // computes (the halo buffer is immutable for the whole slab, so this runs across the per-piece barrier);
-            // weight fragment n+1 (or fragment 0 of the next chunk of the piece) is fetched while fragment n's MFMAs
-            // issue. Every wait counts only the reads issued AFTER the one waited for (LDS returns in order).
+            // ---- software-pipelined K loop (rounds 1-2) -------------------------------------------------------------
+            // Still runs the kernels the newer loops do not cover: the 1x1x1 side convolutions (4-wave workgroups, every precision mode) and the 2-D
+            // nets' one-plane f16 mode (generic halo path). One barrier per weight piece; inside a piece the loop is pipelined by hand:
+            // X fragments of chunk c+1 and the tap offset of chunk c+2 are fetched while chunk c computes (the halo buffer is immutable for the
+            // whole slab, so this runs across the per-piece barrier); weight fragment n+1 (or fragment 0 of the next chunk of the piece) is
+            // fetched while fragment n's MFMAs issue. Every wait counts only the reads issued AFTER the one waited for (LDS returns in order).
+            // (Its round-2 refinements for the 3x3x3 f16m8 kernels - the barrier in front of a piece's last two MFMA groups, prefetch reads spread
+            // over the chunk, weight fragments two groups ahead - went with those kernels' move to the ping-pong loops: profiles/r2/README.md.)
+            static_assert(KS == 1 || (K2D != 0 && SPLIT == 0), "legacy K loop: 1x1x1 layers and the 2-D one-plane f16 mode");
             const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
             unsigned xaddr[MF];
 #pragma unroll
             for (int m = 0; m < MF; ++m) xaddr[m] = xbuf_a + xb * C::XBUF + (unsigned)xbase[m];
             constexpr int NPLM = C::NPLM;
-            // distance 2 pays only where it costs no spills and the MFMA groups are short (r2y: merge_conv_b -1.4 %, merge_conv_a 0, conv4 +10 %)
-            constexpr int WD = (SN_WDIST == 2 && EPI == EPI_FINAL && SPLIT == 2) ? 2 : 1;
-            static_assert(WD == 1 || WD == 2, "weight prefetch distance");
-            // DEFER (f16m8 kernels: pieces are always full): the per-piece barrier sits in front of the LAST TWO MFMA groups of a piece instead of
-            // behind them. Their weight fragments are already in registers (wsp), so after the barrier the wave first requests the next
-            // piece's fragments and issues the next DMAs and THEN runs those 2 x MF MFMAs - the matrix pipe no longer idles through the
-            // cold LDS reads and the DMA issue of every piece start (wave timing: 580 of 4,950 clocks per piece). Pieces that end a slab
-            // keep the barrier at the end (the next slab's set-up has not run yet).
-            constexpr bool DEFER = SN_DEFER && NF >= 4 && (SPLIT == 2 || (SN_DEFER >= 2 && SPLIT == 1 && K2D == 0 && MF * NF <= SN_DEFER_X3_MAXACC && DIL == 1)) && BUFH && !(SN_ABL & 2) && !SN_TIMING && !SN_DMA_LATE;
-            constexpr int NDEF = (SPLIT == 1 && SN_DEFER_X3_GROUPS == 1) ? 1 : 2;   // f16x3: one group = 3 x MF MFMAs already covers the cold reads
-            constexpr int GDEF = C::PCH * NF - NDEF;             // first deferred group of a piece
-            half8 xc[NPLM][MF], xn[NPLM][MF], wr[WD + 1][NPLM], wsp[DEFER ? NDEF : 1][NPLM];
+            half8 xc[NPLM][MF], xn[NPLM][MF], wr[2][NPLM];
             int ko1, ko2;
             auto issue_x = [&](half8(&dst)[NPLM][MF], int ko) {
-                if constexpr (SN_ABL & 32) return;
                 static_for<0, MF>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
                     const unsigned ad = xaddr[m] + (unsigned)ko;
@@ -1414,66 +1174,43 @@ conv3d_f16_mfma(ConvArgs a)
                     }
                 });
             };
-            v4i k4, k4n;                                                      // f16m8: tap offsets of the MX step's 4 groups
-            const unsigned k4_a = koff_a - kq * 4 + (unsigned)(4 * (kq & 1)) * 4;
-            long long k2, k2n;                                                // SN_MX_B128: tap offsets of this lane's 2 groups (8p + 2kq, +1)
+            long long k2, k2n;                                                // f16m8: tap offsets of this lane's 2 groups (8p + 2kq, +1) in the MX step
             const unsigned k2_a = koff_a + kq * 4;
             {
                 int k0;
                 lds_read32<0>(k0, koff_a);
                 lds_read32<16>(ko1, koff_a);
-                if constexpr (SPLIT == 2) {
-                    if constexpr (SN_MX_B128) lds_read64<0>(k2, k2_a);
-                    else lds_read128i<0>(k4, k4_a);
-                }
+                if constexpr (SPLIT == 2) lds_read64<0>(k2, k2_a);
                 lgkm_wait<0>();
                 issue_x(xc, k0);
                 lgkm_wait<0>();
             }
             for (int p = 0; p < npiece; ++p) {
                 const int ch0 = p * C::PCH;
-                // first weight fragment of this piece: issue its LDS read before the (VALU-heavy) DMA address work
                 const unsigned wp = wbuf_a + wbi * C::WBUF;
-                // f16m8: fp8 operands of this piece's MX step; fetched in the middle of the piece (see chunk 1, n == 0)
+                // f16m8: 6-bit operands of this piece's MX step (a slot's 12 code bytes per read); fetched behind the first MFMA group of chunk 0
                 v8i x8[SPLIT == 2 ? MF : 1];
-                long long x8q[SPLIT == 2 ? MF : 1][4];
-                v4i x8h[SPLIT == 2 ? MF : 1][2];
-                v3i x6[SPLIT == 2 ? MF : 1][2];                                    // 6-bit forms: a slot's 12 code bytes
-                auto first_frags = [&](unsigned wpx) {
-                    lds_read128<0>(wr[0][0], wpx);
-                    if constexpr (SPLIT == 1) lds_read128<1024>(wr[0][1], wpx);
-                    if constexpr (WD == 2 && C::PCH * NF > 1) {
-                        lds_read128<C::MFRAG>(wr[1][0], wpx);
-                        if constexpr (SPLIT == 1) lds_read128<C::MFRAG + 1024>(wr[1][1], wpx);
-                    }
-                };
-                const bool defer = DEFER && p + 1 < npiece;                  // this piece hands over to its successor in front of its last two groups
-                if (!DEFER || p == 0) first_frags(wp);                       // (else: requested by the previous piece, behind its barrier)
-                // next weight piece (the following piece of this slab, else the first piece of what comes next) and, behind it, the next
-                // slab's halo tile. SN_DMA_LATE: issued AFTER the first MFMA group of the piece instead of in front of it - every wave of the
-                // workgroup leaves the barrier at the same moment, so DMA issue code in front of the first MFMAs idles the matrix pipe of all
-                // four SIMDs for its whole length; behind the first group it runs under those MFMAs.
+                v3i x6[SPLIT == 2 ? MF : 1][2];
+                // first weight fragment of this piece: its LDS read goes out before the (VALU-heavy) DMA address work
+                lds_read128<0>(wr[0][0], wp);
+                if constexpr (SPLIT == 1) lds_read128<1024>(wr[0][1], wp);
+                // next weight piece (the following piece of this slab, else the first piece of what comes next) and, behind it, the next slab's halo tile
                 int hnow = 0;
-                auto issue_dmas = [&](int p, int ch0, int wbi) {          // at the start of piece p (whose weights are in buffer wbi)
-                    if (p + 1 < npiece) {
-                        const int rem = wchunk - (ch0 + C::PCH);
-                        stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
-                    } else if (have_next) {
-                        const int nch = n_wchunk;
-                        stage_w(nwoff, nch < C::PCH ? nch : C::PCH, wbi ^ 1);
-                    }
-                    if constexpr (BUFH) {
-                        if (have_next && !(SN_ABL & 1) && p == 0)
-                            hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
-                    } else if (have_next && !(SN_ABL & 1) && hdone < HT && (p + 1 < npiece || npiece == 1)) {
-                        const int left = HT - hdone;
-                        const int kn = (p + 2 >= npiece || left < HQ) ? left : HQ;
-                        hnow = stage_halo(ntile, nc0, nc8n, xb ^ 1, hdone, kn);
-                        hdone += kn;
-                    }
-                };
-                if constexpr (!SN_DMA_LATE) { if (!DEFER || p == 0) issue_dmas(p, ch0, wbi); }
-                if constexpr (SN_TIMING == 7 || SN_TIMING == 8) { t_dma = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                if (p + 1 < npiece) {
+                    const int rem = wchunk - (ch0 + C::PCH);
+                    stage_w(woff + (size_t)(ch0 + C::PCH) * NF * C::FRAG, rem < C::PCH ? rem : C::PCH, wbi ^ 1);
+                } else if (have_next) {
+                    stage_w(nwoff, n_wchunk < C::PCH ? n_wchunk : C::PCH, wbi ^ 1);
+                }
+                if constexpr (BUFH) {
+                    if (have_next && p == 0)
+                        hnow = stage_halo_buf(last_slab ? nxt_b : (K2D ? x0 : b), last_slab ? nxt_keep : cur_keep, last_slab ? nxt_toff : cur_toff, nc0, nc8n, xb ^ 1);
+                } else if (have_next && hdone < HT && (p + 1 < npiece || npiece == 1)) {
+                    const int left = HT - hdone;
+                    const int kn = (p + 2 >= npiece || left < HQ) ? left : HQ;
+                    hnow = stage_halo(ntile, nc0, nc8n, xb ^ 1, hdone, kn);
+                    hdone += kn;
+                }
                 static_for<0, C::PCH>([&](auto ccc) {
                     constexpr int cc = decltype(ccc)::value;
                     const int ch = ch0 + cc;
@@ -1482,129 +1219,44 @@ conv3d_f16_mfma(ConvArgs a)
                         static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
                             constexpr int G = cc * NF + n, GT = C::PCH * NF;                     // group index inside the piece / groups of a full piece
-                            constexpr int cur = WD == 2 ? G % 3 : (par0 + n) & 1, nxt = WD == 2 ? (G + 2) % 3 : cur ^ 1;
+                            constexpr int cur = (par0 + n) & 1, nxt = cur ^ 1;
                             constexpr bool more_n = (n + 1 < NF), more_c = (cc + 1 < C::PCH);
-                            // reads issued after this group's fragment and allowed to stay in flight while it is waited for: the fragments of the next
-                            // WD groups, plus (E) the tap offset / activation fragments [/ MX operands] that group 0 of the chunk issues behind its MFMAs
-                            constexpr int E = 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? (SN_MX_B128 ? 2 : 4) * MF + 1 : 0);
-                            // SPR: the E reads are not issued in one burst behind group 0 but PER at a time behind groups 0 .. NF-1-WD. A burst of 14 reads
-                            // per wave (8 waves at once, right after the barrier) filled the LDS queue, and the weight fragment of group WD+1 - issued
-                            // behind the burst, returned in order - made chunk 0 take 1,640 clocks for 450 of MFMA issue (wave timing, SN_TIMING 5)
-                            constexpr bool SPR = SN_ESPREAD && SPLIT == 2 && SN_MX_B128 && NF - WD >= 2;   // (f16x3 / f16 kernels: conv2_x +2 %, the rest unchanged -> burst kept)
-                            constexpr int PER = SPR ? (E + NF - WD - 1) / (NF - WD > 0 ? NF - WD : 1) : E;
-                            constexpr int EQ = sn_e_after(n - 1, E, PER) + (WD == 2 ? sn_e_after(n - 2, E, PER) : 0);   // E reads younger than the awaited fragment
-                            // weight fragment of a later group; the piece's last two groups (DEFER) keep theirs in wsp
-                            constexpr int Gn = WD == 2 ? G + 2 : (more_n ? G + 1 : (cc + 1) * NF);      // the group whose fragment is requested now
-                            if constexpr (Gn < GT && !(SN_ABL & 16)) {
-                                if constexpr (DEFER && Gn >= GDEF) {
-                                    lds_read128<Gn * C::MFRAG>(wsp[Gn - GDEF][0], wp);
-                                    if constexpr (SPLIT == 1) lds_read128<Gn * C::MFRAG + 1024>(wsp[Gn - GDEF][1], wp);
-                                } else {
-                                    lds_read128<Gn * C::MFRAG>(wr[nxt][0], wp);
-                                    if constexpr (SPLIT == 1) lds_read128<Gn * C::MFRAG + 1024>(wr[nxt][1], wp);
-                                }
+                            // reads issued after this group's fragment and allowed to stay in flight while it is waited for: the fragment of the next
+                            // group, plus (E) the tap offset / activation fragments [/ MX operands] that group 0 of the chunk issues behind its MFMAs
+                            constexpr int E = 1 + MF * NPLM + ((SPLIT == 2 && cc == 0) ? 2 * MF + 1 : 0);
+                            constexpr int EQ = sn_e_after(n - 1, E, E);                          // E reads younger than the awaited fragment
+                            constexpr int Gn = more_n ? G + 1 : (cc + 1) * NF;                   // the group whose fragment is requested now
+                            if constexpr (Gn < GT) {
+                                lds_read128<Gn * C::MFRAG>(wr[nxt][0], wp);
+                                if constexpr (SPLIT == 1) lds_read128<Gn * C::MFRAG + 1024>(wr[nxt][1], wp);
                             }
-                            auto group_wait = [&]() {
-                                if constexpr (WD == 2) lgkm_wait<NPLM * ((G + 1 < GT ? 1 : 0) + (G + 2 < GT ? 1 : 0)) + EQ>();
-                                else lgkm_wait<((more_n || more_c) ? NPLM : 0) + EQ>();
-                            };
-                            if constexpr (DEFER && G == GDEF) {
-                                if (defer) {
-                                    // hand the weight buffers over to the next piece HERE: everything this piece still needs is in registers
-                                    lgkm_wait<0>();
-                                    if (hnow >= HQ) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HQ) : "memory");
-                                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                    wg_barrier();
-                                    first_frags(wbuf_a + (wbi ^ 1) * C::WBUF);
-                                } else group_wait();
-                            } else if constexpr (DEFER && G > GDEF) {
-                                if (!defer) group_wait();
-                            } else group_wait();
-                            if constexpr (!(SN_ABL & 4)) {
-                                if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(1);
-                                const half8(&wg)[NPLM] = (DEFER && G >= GDEF) ? wsp[(DEFER && G >= GDEF) ? G - GDEF : 0] : wr[cur];
-                                const half8 &w0 = wg[0];
-                                if constexpr (SPLIT == 1) {
+                            lgkm_wait<((more_n || more_c) ? NPLM : 0) + EQ>();
+                            const half8 &w0 = wr[cur][0];
+                            if constexpr (SPLIT == 1) {
 #pragma unroll
-                                    for (int m = 0; m < MF; ++m)
-                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[1], xc[0][m], acc[m][n], 0, 0, 0);
+                                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][1], xc[0][m], acc[m][n], 0, 0, 0);
 #pragma unroll
-                                    for (int m = 0; m < MF; ++m)
-                                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xc[1][m], acc[m][n], 0, 0, 0);
-                                }
-#pragma unroll
-                                for (int m = 0; m < MF; ++m)
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xc[0][m], acc[m][n], 0, 0, 0);
-                                if constexpr (SN_SETPRIO) __builtin_amdgcn_s_setprio(0);
-                            } else {
-                                asm volatile("" ::"v"(wr[cur][0]), "v"(xc[0][0]));
+                                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xc[1][m], acc[m][n], 0, 0, 0);
                             }
-                            if constexpr (DEFER && G == GDEF) { if (defer) issue_dmas(p + 1, ch0 + C::PCH, wbi ^ 1); }   // under this group's MFMAs
-                            if constexpr (SN_DMA_LATE && cc == 0 && n == 0) issue_dmas(p, ch0, wbi);
-                            if constexpr (SPR) {
-                                constexpr int NX = MF * NPLM;
-                                static_for<0, E>([&](auto rc) {
-                                    constexpr int r = decltype(rc)::value;
-                                    if constexpr (r / PER == n) {
-                                        if constexpr (r == 0) {
-                                            lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
-                                        } else if constexpr (r <= NX) {
-                                            constexpr int m = (r - 1) / NPLM, pl = (r - 1) % NPLM;
-                                            const unsigned ad = xaddr[m] + (unsigned)ko1;
-                                            if constexpr (SN_ABL & 32) {
-                                            } else if constexpr (pl == 0) lds_read128<0>(xn[0][m], ad);
-                                            else if constexpr (C::XPLANE < 65536) lds_read128<(C::XPLANE < 65536 ? C::XPLANE : 0)>(xn[1][m], ad);
-                                            else lds_read128<0>(xn[1][m], ad + C::XPLANE);
-                                        } else if constexpr (r <= NX + 2 * MF) {
-                                            constexpr int m = (r - NX - 1) / 2, sl = (r - NX - 1) % 2;
-                                            const unsigned ad = xaddr[m] + C::XPLANE + (unsigned)(int)(sl ? (k2 >> 32) : k2);
-                                            if constexpr (SN_MX_FMT != 0 && !SN_MX6_B128) lds_read96i<0>(x6[m][sl], ad);   // the 12 code bytes of a slot = half of the lane's 192-bit operand
-                                            else lds_read128i<0>(x8h[m][sl], ad);                         // whole 16-byte slot [fp8(hi) x8 | fp8(lo*2^12) x8]
-                                        } else {
-                                            lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);       // tap offsets of the next piece's MX step
-                                        }
-                                    }
-                                });
-                            } else
+#pragma unroll
+                            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xc[0][m], acc[m][n], 0, 0, 0);
                             if constexpr (n == 0) {
                                 lds_read32<0>(ko2, koff_a + (unsigned)(ch + 2) * 16);
                                 issue_x(xn, ko1);
                                 if constexpr (SPLIT == 2 && cc == 0) {
-                                    // fp8 operand fetch for the MX step that closes this piece (tap offsets k4 were read one
-                                    // piece ahead); also fetch the next piece's tap offsets
+                                    // operand fetch for the MX step that closes this chunk (its tap offsets k2 were read one piece ahead); also the next piece's tap offsets
                                     static_for<0, MF>([&](auto mc) {
                                         constexpr int m = decltype(mc)::value;
-                                        if constexpr (SN_MX_B128 && SN_MX_FMT != 0) {
-                                            const unsigned ad = xaddr[m] + C::XPLANE;               // the 12 code bytes of two slots = the lane's 192-bit operand
-                                            if constexpr (SN_MX6_B128) {
-                                                lds_read128i<0>(x8h[m][0], ad + (unsigned)(int)k2);
-                                                lds_read128i<0>(x8h[m][1], ad + (unsigned)(int)(k2 >> 32));
-                                            } else {
-                                                lds_read96i<0>(x6[m][0], ad + (unsigned)(int)k2);
-                                                lds_read96i<0>(x6[m][1], ad + (unsigned)(int)(k2 >> 32));
-                                            }
-                                        } else if constexpr (SN_MX_B128) {
-                                            const unsigned ad = xaddr[m] + C::XPLANE;               // whole 16-byte slots [fp8(hi) x8 | fp8(lo*2^12) x8]
-                                            lds_read128i<0>(x8h[m][0], ad + (unsigned)(int)k2);
-                                            lds_read128i<0>(x8h[m][1], ad + (unsigned)(int)(k2 >> 32));
-                                        } else {
-                                            const unsigned ad = xaddr[m] + C::XPLANE + (kq >> 1) * 8;   // lanes 0-31: fp8(hi), 32-63: fp8(lo*2^12)
-                                            lds_read64<0>(x8q[m][0], ad + (unsigned)k4[0]);
-                                            lds_read64<0>(x8q[m][1], ad + (unsigned)k4[1]);
-                                            lds_read64<0>(x8q[m][2], ad + (unsigned)k4[2]);
-                                            lds_read64<0>(x8q[m][3], ad + (unsigned)k4[3]);
-                                        }
+                                        const unsigned ad = xaddr[m] + C::XPLANE;               // the 12 code bytes of two slots = the lane's 192-bit operand
+                                        lds_read96i<0>(x6[m][0], ad + (unsigned)(int)k2);
+                                        lds_read96i<0>(x6[m][1], ad + (unsigned)(int)(k2 >> 32));
                                     });
-                                    if constexpr (SN_MX_B128) lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
-                                    else lds_read128i<0>(k4n, k4_a + (unsigned)(8 * (p + 1)) * 4);
+                                    lds_read64<0>(k2n, k2_a + (unsigned)(8 * (p + 1)) * 4);
                                 }
                             }
                         });
-                        // X(c+1), koff(c+2) [, MX operands] landed (the reads E of group 0); of the next chunk's first WD weight fragments those issued
-                        // AFTER E may still be in flight: fragment j of the next chunk is issued at the start of group NF + j - WD of this one
-                        constexpr int GTc = C::PCH * NF;
-                        constexpr int young = WD == 2 ? ((NF >= 3 && (cc + 1) * NF < GTc ? 1 : 0) + (NF >= 2 && (cc + 1) * NF + 1 < GTc ? 1 : 0))
-                                                      : ((cc + 1 < C::PCH && NF >= 2) ? 1 : 0);
+                        // X(c+1), koff(c+2) [, MX operands] landed (the reads E of group 0); the next chunk's first weight fragment, issued AFTER E, may still be in flight
+                        constexpr int young = (cc + 1 < C::PCH && NF >= 2) ? 1 : 0;
                         lgkm_wait<NPLM * young>();
 #pragma unroll
                         for (int m = 0; m < MF; ++m) {
@@ -1613,120 +1265,50 @@ conv3d_f16_mfma(ConvArgs a)
                         }
                         ko1 = ko2;
                     }
-                    if constexpr (SN_TIMING >= 5 && cc == 0) { t_c0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-                    if constexpr (SPLIT == 2 && cc == 0 && !(SN_ABL & 256)) {
-                        // MX step (placed between the piece's two f16 chunks so the fp8 operands are short-lived): both correction
-                        // terms of this piece's 64 k in one fp8 MFMA per (cout, voxel) fragment pair;
-                        // scale_a = 2^-12 (E8M0 115): the packed lo parts were multiplied by 2^12
+                    if constexpr (SPLIT == 2 && cc == 0) {
+                        // MX step (placed between the piece's two f16 chunks so its operands are short-lived): both correction terms of this piece's 64 k
+                        // in one MX-scaled MFMA per (cout, voxel) fragment pair
+                        static_assert(SN_MX_FMT != 0 && NF <= 8, "the 6-bit MX forms use the two-slot operand layout");
                         constexpr int mxo = 2 * NF * 1024;
-    #pragma unroll
+#pragma unroll
                         for (int m = 0; m < MF; ++m) {
-                            if constexpr (SN_MX_B128 && SN_MX_FMT != 0) {
-                                // the second slot's three dwords cannot be read in place (a register tuple starts on an even register): 3 v_mov's per
-                                // fragment. Tried: reading it as 32 + 64 bits (lands in place, but the 64-bit read is 4-byte aligned) - merge_conv_b +23 %
-                                // SN_MX6_B128: the slots are read whole (ds_read_b128: 4.6 LDS clocks per wave instruction under load, ds_read_b96: 8.4;
-                                // tools/probe/lds_probe.hip) and the pad dword of the first is overwritten when the second is moved down by one register
-                                if constexpr (SN_MX6_B128) {
-                                    // (the empty asm pins the copies BEHIND the chunk-end wait: to the compiler the registers were complete when the
-                                    // reads were issued, and it is free to move plain copies of them up there)
-                                    asm volatile("" : "+v"(x8h[m][0]), "+v"(x8h[m][1]));
-                                    x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 4, 5, 6, -1, -1);
-                                }
-                                else {
-                                    asm volatile("" : "+v"(x6[m][0]), "+v"(x6[m][1]));
-                                    x8[m] = __builtin_shufflevector(x6[m][0], x6[m][1], 0, 1, 2, 3, 4, 5, -1, -1);
-                                }
-                            } else if constexpr (SN_MX_B128) {
-                                x8[m] = __builtin_shufflevector(x8h[m][0], x8h[m][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                            } else {
-                                x8[m][0] = (int)x8q[m][0]; x8[m][1] = (int)(x8q[m][0] >> 32); x8[m][2] = (int)x8q[m][1]; x8[m][3] = (int)(x8q[m][1] >> 32);
-                                x8[m][4] = (int)x8q[m][2]; x8[m][5] = (int)(x8q[m][2] >> 32); x8[m][6] = (int)x8q[m][3]; x8[m][7] = (int)(x8q[m][3] >> 32);
-                            }
+                            // the second slot's three dwords cannot be read in place (a register tuple starts on an even register): 3 v_mov's per fragment.
+                            // (the empty asm pins the copies BEHIND the chunk-end wait: to the compiler the registers were complete when the reads were issued)
+                            asm volatile("" : "+v"(x6[m][0]), "+v"(x6[m][1]));
+                            x8[m] = __builtin_shufflevector(x6[m][0], x6[m][1], 0, 1, 2, 3, 4, 5, -1, -1);
                         }
-                        if constexpr (SN_MX_B128) k2 = k2n; else k4 = k4n;
-                        if constexpr (SN_MX_FMT != 0) {
-                            // 6-bit operands: the weight fragment of a lane is its 192-bit operand, dwords 0..3 in the first lane-linear KiB of the
-                            // fragment and 4..5 in the second: a 128-bit and a 64-bit read into 6 consecutive registers (register tuples start on even
-                            // registers, so any other split costs v_mov's). The E8M0 block scales of the lane's NF fragments are the 8 bytes behind
-                            // dwords 4..5 of fragment 0: one 64-bit read per piece, the byte is picked by the instruction's op_sel (pack_conv).
-                            static_assert(SN_MX_B128 && NF <= 8, "the 6-bit MX forms use the two-slot operand layout");
-                            v4i wa4[2];
-                            long long wb2[2], wsc;
-                            lds_read64<mxo + 1024 + 8>(wsc, wp);
-                            lds_read128i<mxo>(wa4[0], wp);
-                            lds_read64<mxo + 1024>(wb2[0], wp);
-                            static_for<0, NF>([&](auto nc) {
-                                constexpr int n = decltype(nc)::value;
-                                constexpr int cur = n & 1, nxt = cur ^ 1;
-                                if constexpr (n + 1 < NF) {
-                                    lds_read128i<mxo + (n + 1) * 2048>(wa4[nxt], wp);
-                                    lds_read64<mxo + (n + 1) * 2048 + 1024>(wb2[nxt], wp);
-                                }
-                                lgkm_wait<(n + 1 < NF) ? 2 : 0>();
-                                v8i wa;
-                                wa[0] = wa4[cur][0]; wa[1] = wa4[cur][1]; wa[2] = wa4[cur][2]; wa[3] = wa4[cur][3];
-                                wa[4] = (int)wb2[cur]; wa[5] = (int)(wb2[cur] >> 32); wa[6] = 0; wa[7] = 0;
-                                const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
-                                if constexpr (!(SN_ABL & (4 | 128))) {
-    #pragma unroll
-                                    for (int m = 0; m < MF; ++m)
-                                        acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
-                                }
-                            });
-                        } else {
-                        v4i w8[2][2];
-                        lds_read128i<mxo>(w8[0][0], wp);
-                        lds_read128i<mxo + 1024>(w8[0][1], wp);
+                        k2 = k2n;
+                        // the weight fragment of a lane is its 192-bit operand, dwords 0..3 in the first lane-linear KiB of the fragment and 4..5 in the second: a
+                        // 128-bit and a 64-bit read into 6 consecutive registers. The E8M0 block scales of the lane's NF fragments are the 8 bytes behind
+                        // dwords 4..5 of fragment 0: one 64-bit read per piece, the byte is picked by the instruction's op_sel (pack_conv).
+                        v4i wa4[2];
+                        long long wb2[2], wsc;
+                        lds_read64<mxo + 1024 + 8>(wsc, wp);
+                        lds_read128i<mxo>(wa4[0], wp);
+                        lds_read64<mxo + 1024>(wb2[0], wp);
                         static_for<0, NF>([&](auto nc) {
                             constexpr int n = decltype(nc)::value;
                             constexpr int cur = n & 1, nxt = cur ^ 1;
                             if constexpr (n + 1 < NF) {
-                                lds_read128i<mxo + (n + 1) * 2048>(w8[nxt][0], wp);
-                                lds_read128i<mxo + (n + 1) * 2048 + 1024>(w8[nxt][1], wp);
+                                lds_read128i<mxo + (n + 1) * 2048>(wa4[nxt], wp);
+                                lds_read64<mxo + (n + 1) * 2048 + 1024>(wb2[nxt], wp);
                             }
                             lgkm_wait<(n + 1 < NF) ? 2 : 0>();
                             v8i wa;
-                            wa[0] = w8[cur][0][0]; wa[1] = w8[cur][0][1]; wa[2] = w8[cur][0][2]; wa[3] = w8[cur][0][3];
-                            wa[4] = w8[cur][1][0]; wa[5] = w8[cur][1][1]; wa[6] = w8[cur][1][2]; wa[7] = w8[cur][1][3];
-                            if constexpr (!(SN_ABL & (4 | 128))) {
-    #pragma unroll
-                                for (int m = 0; m < MF; ++m)
-                                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, x8[m], acc[m][n], 0, 0, 0, 115, 0, 127);
-                            }
+                            wa[0] = wa4[cur][0]; wa[1] = wa4[cur][1]; wa[2] = wa4[cur][2]; wa[3] = wa4[cur][3];
+                            wa[4] = (int)wb2[cur]; wa[5] = (int)(wb2[cur] >> 32); wa[6] = 0; wa[7] = 0;
+                            const int sa = n < 4 ? (int)wsc : (int)(wsc >> 32);
+#pragma unroll
+                            for (int m = 0; m < MF; ++m)
+                                acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, x8[m], acc[m][n], SN_MX_FMT, SN_MX_FMT, n & 3, sa, 0, mx_sb);
                         });
-                        }
-                        if constexpr (SN_TIMING >= 3) { t_mx = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                     }
                 });
                 lgkm_wait<0>();
-                if constexpr (!(SN_ABL & 2)) if (!defer) {
-                    long long tq0 = 0, tq1 = 0;
-                    if constexpr (SN_TIMING) { tq0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-                    // next weight piece landed; the newest HQ halo DMAs (issued after it) may still fly
-                    if (p + 1 != npiece && hnow >= HQ) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HQ) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if constexpr (SN_TIMING) { tq1 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-                    wg_barrier();                             // ... for every wave; this piece's buffers are free again
-                    if constexpr (SN_TIMING >= 1 && SN_TIMING <= 8) {      // (9, 10: modes of the ping-pong loops / per tile)
-                        const long long tq2 = __builtin_readcyclecounter();
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if constexpr (SN_TIMING >= 7) {       // 7 / 8: [1] += piece start -> weight DMAs issued (and the first fragments landed), [2] += the rest of chunk 0
-                            if ((SN_TIMING == 7) == (wave >= C::NW / 2) && t_rel != 0 && p != 0) { t_vm += t_dma - t_rel; t_bar += t_c0 - t_dma; }
-                            t_rel = tq2;
-                        } else if constexpr (SN_TIMING >= 5) {       // 5 / 6 (waves >= NW/2 / < NW/2): [1] += piece start -> end of chunk 0, [2] += end of chunk 0 -> MX step done
-                            if ((SN_TIMING == 5) == (wave >= C::NW / 2) && t_rel != 0 && p != 0) { t_vm += t_c0 - t_rel; t_bar += t_mx - t_c0; }
-                            t_rel = tq2;
-                        } else if constexpr (SN_TIMING >= 3) { // 3 / 4: [1] += piece start -> MX step done, [2] += MX step done -> end of chunk 1 (pieces p > 0 of a slab)
-                            if ((SN_TIMING == 3) == (wave >= C::NW / 2) && t_rel != 0 && p != 0) { t_vm += t_mx - t_rel; t_bar += tq0 - t_mx; }
-                            t_rel = tq2;
-                        } else { t_vm += tq1 - tq0; t_bar += tq2 - tq1; }
-                        if (EPI == EPI_FINAL && a.status && blockIdx.x == 0 && n_piece < 2048 && lane == 0) {     // trace of workgroup 0: [piece][wave]{arrive, release}
-                            long long *tr = reinterpret_cast<long long *>(a.status + 2 + 32 * 8) + ((size_t)n_piece * C::NW + wave) * 2;
-                            tr[0] = tq1; tr[1] = tq2;
-                        }
-                        ++n_piece;
-                    }
-                }
+                // next weight piece landed; the newest HQ halo DMAs (issued after it) may still fly
+                if (p + 1 != npiece && hnow >= HQ) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HQ) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wg_barrier();                             // ... for every wave; this piece's buffers are free again
                 wbi ^= 1;
             }
             }
@@ -1737,7 +1319,7 @@ conv3d_f16_mfma(ConvArgs a)
             if constexpr (PWM) pw_hptr += VOL * 16;
         }
 
-        if constexpr (PP && SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }     // pairs with group 1's last compute segment of the tile
+        if constexpr (PP) { if (wave < C::NW / 2) wg_barrier(); }     // pairs with group 1's last compute segment of the tile
         if constexpr (PWM) {      // the loop's MFMAs are inline asm: the wait states between the last of them and the epilogue's accumulator reads, by hand
 #pragma unroll
             for (int m = 0; m < MF; ++m)
@@ -1748,13 +1330,7 @@ conv3d_f16_mfma(ConvArgs a)
         const long long t_tile1 = SN_TIMING == 10 ? __builtin_readcyclecounter() : 0;
         if constexpr (SN_TIMING == 10) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- epilogue: folded BN affine + activation --------------------------------------------------------
-        if constexpr (EPI == EPI_STORE && (SN_ABL & 512)) {
-            // ablation 512: keep the accumulators live, store nothing
-#pragma unroll
-            for (int m = 0; m < MF; ++m)
-#pragma unroll
-                for (int n = 0; n < NF; ++n) asm volatile("" ::"v"(acc[m][n]));
-        } else if constexpr (EPI == EPI_POOL2D) {
+        if constexpr (EPI == EPI_POOL2D) {
             // conv + bias + ReLU, then Pool2DLayer(2) in registers: the 2x2 pixel quad of an output lives in lanes {l, l^1} (columns)
             // x {l, l^8} (rows; l^4 for the 4x4-image fragments). max(split(y)) == split(max(y)) bit for bit because the
             // hi/lo rounding is monotone, so this equals storing the map and max-pooling the stored values. Output: [c/8][DX][D/2][D/2][8].
@@ -1762,9 +1338,9 @@ conv3d_f16_mfma(ConvArgs a)
             const int Do = D >> 1;
             const size_t VOLo = (size_t)DX * Do * Do;
             constexpr int YX = C::F4 ? 4 : 8;                       // lane distance of the row partner
-            // R2: the two rows of a fragment lie 2 apart (conflict-free LDS reads, SN_ROWGAP_2D): the row partner of a pixel is the SAME lane of
+            // R2: the two rows of a fragment are not adjacent (conflict-free LDS reads, kRowGap2D): the row partner of a pixel is the SAME lane of
             // fragment m ^ 1 (rows r and r + 1), every lane row of fragment m = 0, 2 writes one pooled row
-            constexpr bool R2 = (K2D == 1 && (SN_ROWGAP_2D == 2 || SN_ROWGAP_2D == 4) && C::VS == 32);   // (64-byte pixels, f16 mode: adjacent rows are already 640 bytes apart)
+            constexpr bool R2 = (K2D == 1 && C::VS == 32);   // (64-byte pixels, f16 mode: adjacent rows are already 640 bytes apart)
             f32x4 scv[NF], shv[NF];           // all fragments' constants before the first store (see EPI_STORE)
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
@@ -1941,17 +1517,17 @@ conv3d_f16_mfma(ConvArgs a)
             }
             // ---- 2x2x2 max-pool in registers: x partner = fragment mm+2, y partner = lane ^ 8, z partner = lane ^ 1; stored in the layer's
             // own format (max(split(y)) == split(max(y)): the hi/lo rounding is monotone, so this equals pooling the stored tensor)
-            // SN_PMAP_GAP4: a fragment's rows lie 4 apart (conflict-free LDS reads, lds_probe): wave w owns rows {k, k+1, k+4, k+5}, k = 2 (w >> 2);
+            // A fragment's rows lie 4 apart (conflict-free LDS reads, lds_probe): wave w owns rows {k, k+1, k+4, k+5}, k = 2 (w >> 2);
             // the y partner is the same lane of fragment m ^ 1, so all four fragments of the wave collapse into ONE pooled value per lane pair
             // (MF = 8: the wave's fragments 4..7 are a second pair of x-slices: the same once more)
 #pragma unroll
             for (int mset = 0; mset < MF; mset += 4)
 #pragma unroll
-            for (int mm = mset; mm < mset + (SN_PMAP_GAP4 ? 1 : 2); ++mm) {
+            for (int mm = mset; mm < mset + 1; ++mm) {
                 int hx, hy, hz;
                 frag_xyz(mm, hx, hy, hz);
                 const int gx = x0 + hx, gy = y0 + hy, gz = z0 + hz;
-                const bool writer = !(v & 1) && (SN_PMAP_GAP4 || !(v & 8)) && gx < DX && gy < D && gz < D;     // D even: the whole cell is inside
+                const bool writer = !(v & 1) && gx < DX && gy < D && gz < D;     // D even: the whole cell is inside
                 // per-lane part of the store address as ONE 32-bit byte offset (pooled voxel, the lane's half of its 8-channel group, + one group
                 // plane for kq >= 2), the rest wave-uniform: see EPI_STORE (a spilled 64-bit address reloaded inside the store loop = vmcnt(0) per store)
                 const unsigned pvoff = ((unsigned)(((gx >> 1) * Do + (gy >> 1)) * Do + (gz >> 1)) + (unsigned)(kq >> 1) * (unsigned)VOLo) * 16u + (unsigned)(kq & 1) * 8u;
@@ -1962,8 +1538,7 @@ conv3d_f16_mfma(ConvArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float t = fmaxf(y[mm][n][r], y[mm + 2][n][r]);
-                        if constexpr (SN_PMAP_GAP4) t = fmaxf(t, fmaxf(y[mset + 1][n][r], y[mset + 3][n][r]));
-                        else t = fmaxf(t, __shfl_xor(t, 8));
+                        t = fmaxf(t, fmaxf(y[mset + 1][n][r], y[mset + 3][n][r]));
                         t = fmaxf(t, __shfl_xor(t, 1));
                         if constexpr (SPLIT == 1) {
                             _Float16 hh, ll;
@@ -2042,8 +1617,7 @@ conv3d_f16_mfma(ConvArgs a)
                 frag_xyz(mp + (odd ? 1 : 0), hx_, hy_, hz_);
                 const int gx = x0 + hx_, gy = y0 + hy_, gz = z0 + hz_;
                 const bool my_valid = gx < DX && gy < D && gz < D;
-                const unsigned my_voff = (SN_ABL & 1024) ? ((unsigned)((hx_ * D + hy_) * D + hz_) + (unsigned)(kq >> 1) * (unsigned)VOL) * 16u   // ablation 1024: every tile writes tile 0's slots (L2-resident)
-                                                         : ((unsigned)((gx * D + gy) * D + gz) + (unsigned)(kq >> 1) * (unsigned)VOL) * 16u;
+                const unsigned my_voff = ((unsigned)((gx * D + gy) * D + gz) + (unsigned)(kq >> 1) * (unsigned)VOL) * 16u;
 #pragma unroll
                 for (int n = 0; n < NF; ++n) {
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
@@ -2097,11 +1671,10 @@ conv3d_f16_mfma(ConvArgs a)
                     const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
                     const auto h1 = __builtin_amdgcn_permlane16_swap(hw[0][1], hw[1][1], false, false);
                     const int g0 = (a.out_coff + (blockIdx.y * NF + n) * 16) >> 3;      // first 8-channel group of fragment n (out_coff is a multiple of 8)
-                    char *const plane = reinterpret_cast<char *>(a.out) + 2 * ((size_t)((SN_ABL & 1024) ? 0 : b) * VOL * a.out_cs + (size_t)g0 * VOL * 8);     // wave-uniform
+                    char *const plane = reinterpret_cast<char *>(a.out) + 2 * ((size_t)b * VOL * a.out_cs + (size_t)g0 * VOL * 8);     // wave-uniform
                     _Float16 *o = reinterpret_cast<_Float16 *>(plane + my_voff);
                     const bool st = my_valid && ch_ok;
                     if (st) *reinterpret_cast<u32x4 *>(o) = u32x4{h0[0], h1[0], h0[1], h1[1]};
-                    if constexpr (SN_ABL & 2048) { if (st) { const u32x4 dv = u32x4{h0[0], h1[0], h0[1], h1[1]}; asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(o), "v"(dv) : "memory"); } }   // ablation 2048: every hi-plane store issued twice
                     if constexpr (OSPLIT == 1) {
                         const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
                         const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
@@ -2165,7 +1738,6 @@ conv3d_f16_mfma(ConvArgs a)
         }
         if constexpr (SN_TIMING == 10) { const long long t_tile2 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_vm += t_tile2 - t_tile1; t_bar += t_tile1 - t_tile0; ++n_piece; }
     }
-    if constexpr (PP && !SN_PP_RESYNC) { if (wave < C::NW / 2) wg_barrier(); }       // pairs with group 1's last compute segment
     bad |= sn_tracked_bad(trk_acc, trk_h);
     if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, a.status_bit);
     if (a.status && a.mx_sat_bits != 0 && __builtin_amdgcn_ballot_w64(sn_tracked_max_bits(trk_h) > a.mx_sat_bits) != 0 && lane == 0) atomicOr(a.status + 1, a.status_bit);

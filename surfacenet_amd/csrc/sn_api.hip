@@ -247,10 +247,9 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
                                 continue;
                             }
                             for (int i = 0; i < 4; ++i) {
-                                // SN_MX_B128: lane quarter q covers groups 8p+2q, 8p+2q+1, 8-byte sections [w_lo | w_hi | w_lo | w_hi] (the
-                                // activation slots read [x_hi | x_lo]); else: q<2 -> w_lo, q>=2 -> w_hi of the 4 groups 8p + 4(q&1) + i
-                                const int g = SN_MX_B128 ? 8 * p + 2 * q + (i >> 1) : 8 * p + 4 * (q & 1) + i;
-                                const bool lo_part = SN_MX_B128 ? !(i & 1) : q < 2;
+                                // fp8 form: lane quarter q covers groups 8p+2q, 8p+2q+1, 8-byte sections [w_lo | w_hi | w_lo | w_hi] (the activation slots read [x_hi | x_lo])
+                                const int g = 8 * p + 2 * q + (i >> 1);
+                                const bool lo_part = !(i & 1);
                                 if (g >= G) continue;
                                 for (int j = 0; j < 8; ++j) {
                                     const float w = wslot(o, g, j);
@@ -326,8 +325,8 @@ static TileChoice tile_for(const LayerSpec &sp, int split)
     if (sp.kind == K_CONV1 || sp.kind == K_DIL1) return {1, 1, 5};
     if (sp.kind == K_DIL3) return {5, 4, 1};        // conv4: dilation-2 halo is big -> 8-channel slabs; 4 x 80 output channels
     if (sp.cout == 32) return {2, 1, 1};
-    if (sp.cout == 80) return {5, 1, (split == 2 || SN_PPX) ? 1 : 2};
-    if (sp.cout == 160) return {5, 2, (split == 2 || SN_PPX) ? 1 : 2};
+    if (sp.cout == 80) return {5, 1, 1};
+    if (sp.cout == 160) return {5, 2, 1};
     // cout 100 (merge_conv_a/b). f16 mode has LDS room for two 8-channel groups per slab in merge_conv_a (-18 % there)
     return {7, 1, (split == 0 && sp.cin == 64) ? 2 : 1};
 }
@@ -373,18 +372,13 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
               ma = A(c->ma, v1, 104), none = Act{nullptr, 0};
     int rc;
 #define RUN(x) do { if ((rc = (x)) != SN_OK) return rc; } while (0)
-#ifndef SN_C1_MF
-#define SN_C1_MF 8        // voxel fragments per wave of conv1_1 / conv1_2: 8 = 16x8x8 tiles (half the weight staging and weight-fragment reads per MFMA: -6..7 %, A/B r3l), 4-chunk weight pieces - the LDS holds no more
-#endif
-#ifndef SN_C13_MF
-#define SN_C13_MF 8
-#endif
-#define CONV1 3, 1, SN_C1_MF, 2, EPI_STORE, SP, 1, (SP == 2 ? 2 : (SN_C1_MF == 8 ? 4 : 7)), 8, 0
+// conv1_x: 8 voxel fragments per wave = 16x8x8 tiles (half the weight staging and weight-fragment reads per MFMA of an 8x8x8 tile: -6..7 %, A/B r3l),
+// 4-chunk weight pieces - the LDS holds no more
+#define CONV1 3, 1, 8, 2, EPI_STORE, SP, 1, (SP == 2 ? 2 : 4), 8, 0
 #define SIDE  1, 1, 4, 1, EPI_STORE, SP, 5, 2, 4, 0
-// conv2_x / conv3_x: 16-channel slabs with one-chunk weight pieces; the ping-pong loop (SN_PPX) needs >= 2 chunks per piece, which fits the
-// LDS only with 8-channel slabs (4-chunk pieces: a 7-chunk slab = pieces of 4 + 3)
-#define C23_CS8 (SP == 2 ? 1 : (SN_PPX ? 1 : 2))
-#define C23_PCH (SP == 2 ? 2 : (SN_PPX ? 4 : 1))
+// conv2_x / conv3_x: the ping-pong loop needs >= 2 chunks per weight piece, which fits the LDS only with 8-channel slabs (4-chunk pieces: a 7-chunk slab = pieces of 4 + 3)
+#define C23_CS8 1
+#define C23_PCH (SP == 2 ? 2 : 4)
 #define CONV2 3, 1, 4, 5, EPI_STORE, SP, C23_CS8, C23_PCH, 8, 0
 #define CONV3 3, 1, 4, 5, EPI_STORE, SP, C23_CS8, C23_PCH, 8, 0
 #define CONV4 3, 2, 4, 5, EPI_STORE, SP, 1, 2, 8, 0
@@ -402,8 +396,8 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     static const bool unfused = sn_ab_switch("SN_NO_EPI_FUSION") != nullptr;      // A/B measurements: the three separate launches
     if (!unfused) {
         const SideFuse sf1{&L["side_op1"], cat, 64, 0, p1, 32};
-        // (f16x3: 16x8x8 tiles as conv1_1 / conv1_2, SN_C13_MF = 8: half the weight staging and weight reads per MFMA)
-        if (cat_m8) { if constexpr (SP == 1) RUN((launch_conv<3, 1, SN_C13_MF, 2, EPI_SIDEPOOL, 1, 1, (SN_C13_MF == 8 ? 4 : 7), 8, 0, 0, 2>(c, L["conv1_3"], b1, 32, none, 0, 0, 32, nullptr, S, s, 0, &sf1))); }
+        // (f16x3: 16x8x8 tiles as conv1_1 / conv1_2)
+        if (cat_m8) { if constexpr (SP == 1) RUN((launch_conv<3, 1, 8, 2, EPI_SIDEPOOL, 1, 1, 4, 8, 0, 0, 2>(c, L["conv1_3"], b1, 32, none, 0, 0, 32, nullptr, S, s, 0, &sf1))); }
         else RUN((launch_conv<3, 1, 4, 2, EPI_SIDEPOOL, SP, 1, (SP == 2 ? 2 : 7), 8, 0>(c, L["conv1_3"], b1, 32, none, 0, 0, 32, nullptr, S, s, 0, &sf1)));
     } else {
         RUN((launch_conv<CONV1>(c, L["conv1_3"], b1, 32, a1, 32, 0, 32, nullptr, S, s)));
@@ -461,20 +455,9 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     else RUN((launch_up3<SP>(c, s2, s3, s4, cat, S, s, 64)));
     if constexpr (SP == 1) {
         if (c->tail_m8 >= 2) {
-            // SN_PW (round 4): 4-wave workgroups, one wave per SIMD with 8 x 7 fragment tiles (conv3d_mfma.h, PWM loop); bit 0: merge_conv_a, bit 1: merge_conv_b
-#ifndef SN_PW_LAYERS
-#define SN_PW_LAYERS 3
-#endif
-            if constexpr ((SN_PW != 0) && (SN_PW_LAYERS & 1) != 0) RUN((launch_conv<3, 1, 8, 7, EPI_STORE, 2, 1, 2, 4, 0>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
-            else RUN((launch_conv<3, 1, 4, 7, EPI_STORE, 2, 1, 2, 8, 0>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
-            if constexpr ((SN_PW != 0) && (SN_PW_LAYERS & 2) != 0) RUN((launch_conv<3, 1, 8, 7, EPI_FINAL, 2, 1, 2, 4, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
-            else RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
-            return SN_OK;
-        }
-        if (c->tail_m8 == 1) {
-            // merge_conv_a (three-fp16-MFMA) writes its output in the f16m8 storage format and merge_conv_b computes in f16m8
-            RUN((launch_conv<3, 1, 4, 7, EPI_STORE, 1, 1, 2, 8, 0, 0, 2>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
-            RUN((launch_conv<3, 1, 4, 7, EPI_FINAL, 2, 1, 2, 8, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
+            // 4-wave workgroups, one wave per SIMD with 8 x 7 fragment tiles and the accumulators in AGPRs (conv3d_mfma.h, the one-wave-per-SIMD loop)
+            RUN((launch_conv<3, 1, 8, 7, EPI_STORE, 2, 1, 2, 4, 0>(c, L["merge_conv_a"], cat, 64, ma, 104, 0, 104, nullptr, S, s)));
+            RUN((launch_conv<3, 1, 8, 7, EPI_FINAL, 2, 1, 2, 4, 0>(c, L["merge_conv_b"], ma, 104, none, 0, 0, 0, unf, S, s)));
             return SN_OK;
         }
     }
@@ -645,7 +628,7 @@ int sn_set_precision(sn_ctx *c, int mode)
     // (dtu_real: L_inf 4.4e-4 on the device, 4.7e-4 in the model of the arithmetic; profiles/r5/format_table_*.json). Test-only twin: SN_C4_M6=1.
     c->c4_m6 = false;
     if (mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0 && sn_ab_switch("SN_C4_M6")) c->c4_m6 = atoi(sn_ab_switch("SN_C4_M6")) != 0;
-    if (mode == SN_PRECISION_F16X3 && sn_ab_switch("SN_M8_TAIL")) c->tail_m8 = std::max(0, std::min(2, atoi(sn_ab_switch("SN_M8_TAIL"))));   // A/B measurements only
+    if (mode == SN_PRECISION_F16X3 && sn_ab_switch("SN_M8_TAIL")) c->tail_m8 = atoi(sn_ab_switch("SN_M8_TAIL")) >= 2 ? 2 : 0;   // A/B measurements only (0 = f16x3p's arithmetic)
     if (c->tail_m8 < 2) c->c4_m6 = false;
     reset_mx_exponents(c);
     return SN_OK;
@@ -866,7 +849,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
         }
         PackedConv L;
         L.name = sp.name; L.cin = sp.cin; L.cout = sp.cout; L.ks = k; L.dil = (sp.kind == K_DIL3) ? 2 : 1; L.act = sp.act;
-        const int lsplit = (c->split == 1 && ((c->tail_m8 >= 1 && L.name == "merge_conv_b") || (c->tail_m8 >= 2 && L.name == "merge_conv_a") ||
+        const int lsplit = (c->split == 1 && ((c->tail_m8 >= 2 && (L.name == "merge_conv_b" || L.name == "merge_conv_a")) ||
                                               (c->c4_m6 && sp.kind == K_DIL3))) ? 2 : c->split;   // see run_net_t
         const TileChoice tc = tile_for(sp, lsplit);
         std::vector<int> &oe = out_exps[sp.name];
@@ -877,7 +860,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
                 if (m > 0.f && std::isfinite(m)) oe[o] = std::max(-60, std::min(60, -std::ilogb(m)));
             }
         static const bool no_bridge = sn_ab_switch("SN_NO_BRIDGE") != nullptr;               // (A/B switch)
-        L.bridge = (((SN_PPX && lsplit == 1) || ((SN_PP || SN_PW) && lsplit == 2)) && k == 3 && !no_bridge) ? 1 : 0;   // 27 K-chunks per four slabs instead of 28 (f16x3), 27 weight pieces per eight slabs instead of 32 (f16m8): pack_conv_host decides
+        L.bridge = ((lsplit == 1 || lsplit == 2) && k == 3 && !no_bridge) ? 1 : 0;   // 27 K-chunks per four slabs instead of 28 (f16x3), 27 weight pieces per eight slabs instead of 32 (f16m8): pack_conv_host decides
         if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit, in_exp, oe.data())) != SN_OK) return rc;
         c->conv[L.name] = L;
     }

@@ -105,8 +105,7 @@ struct sn_ctx {
     bool c4_m6 = false;         // EXPERIMENT (off), round 5: conv4_1 .. conv4_3 with their correction terms on the 6-bit MX MFMA (1.5 MFMA units per product instead of 3)
     _Float16 *a3c = nullptr;    // code plane of conv3_3's output (x3_to_m6_kernel), [max_samples][160/8][D/4]^3 slots of 16 bytes
     int mx_act_e8 = kMxActE8, mx_cat_e8 = kMxCatE8;   // mx_format.h; SN_MX_S_ACT / SN_MX_S_CAT in the environment override them in the default (hybrid) mode
-    int tail_m8 = 2;            // f16x3: how many of the last 3x3x3 layers run their two correction terms on the MX-fp8 MFMA
-                                // (0 none = f16x3p, 1 merge_conv_b, 2 merge_conv_a + merge_conv_b); env SN_M8_TAIL overrides (A/B runs)
+    int tail_m8 = 2;            // f16x3: 2 = merge_conv_a + merge_conv_b run their two correction terms on the MX MFMA (the default), 0 = none (f16x3p)
     bool ws_ready = false; int ws_split = -1;
     int last_run_samples = 0;   // samples of the last network run whose activations are still in the workspace (0: none since the weights / mode changed) - sn_calibrate_dev
     std::map<std::string, PackedConv> conv;
@@ -323,17 +322,6 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     // persistent workgroups: one resident set, each walking tiles blockIdx.x, +gridDim.x, ...
     const int resident = std::max(1, c->num_cus * C::WG_PER_CU / L.nsplit);
     dim3 grid((unsigned)std::min(a.total_tiles, resident), (unsigned)L.nsplit);
-    {
-        // phase-staggered start (only worthwhile when every workgroup walks many tiles): a quarter of the estimated tile time
-        static const int stag = sn_ab_switch("SN_STAGGER") ? atoi(sn_ab_switch("SN_STAGGER")) : 0;
-        const int tiles_per_wg = a.total_tiles / (int)grid.x;
-        if (stag && EPI == EPI_STORE && tiles_per_wg >= 8) {
-            double chunks = 0;
-            for (unsigned char c8n : L.slab_c8) chunks += (C::NTAP * c8n + 3) / 4;
-            const double units = chunks * MF * NF * (SPLIT == 1 ? 3.0 : (SPLIT == 2 ? 2.2 : 1.0));
-            a.stagger_clk = (int)(units * 19.5 * 2.0 * 1.3 / 4.0) * stag;
-        }
-    }
     hipLaunchKernelGGL((conv3d_f16_mfma<KS, DIL, MF, NF, EPI, SPLIT, CS8, PCH, NW, PADV, K2D, OSPLIT>), grid, dim3(NW * 64), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return SN_OK;

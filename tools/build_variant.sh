@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_variant.sh NAME [-DFLAG ...]  ->  gpurun_abl/NAME/libsurfacenet_hip.so
-# A/B builds of the HIP library with extra compile-time switches (SN_PP, SN_WDIST, ...). gpurun_abl/ is git-ignored but travels to the
+# A/B builds of the HIP library with extra compile-time switches (SN_TIMING, SN_MX_S_ACT, ...). gpurun_abl/ is git-ignored but travels to the
 # GPU box; select a variant at run time with SURFACENET_HIP_LIB=gpurun_abl/NAME/libsurfacenet_hip.so (surfacenet_amd/_lib.py).
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"

@@ -3,11 +3,11 @@
     hipcc ... -DSN_TIMING=1 (conv3d_mfma.h) -> SURFACENET_HIP_LIB=<that .so> python tools/wave_timing.py
 Every wave accumulates shader-clock totals (whole kernel, the vmcnt wait in front of each per-piece barrier, the barrier itself); the
 script runs the headline batch a few times and prints, per layer, the share of wave time spent in the two waits.
--DSN_TIMING=1..6, 9 (ping-pong f16m8 kernels, i.e. merge_conv_a/b): the two columns hold SEGMENT times instead - 1: {load, wait at the barrier},
-2: {MFMA burst, wait}, 3 / 4: the same for the MX segments only, 5 / 6: for the f16 segments only, 9: {the MX segments' vmcnt wait, everything in
-front of it}; "pieces" then counts segments. -DSN_TIMING=10 (every conv kernel): per TILE {store epilogue, K loop}. 3..8 on the pipelined loop
-(kernels the ping-pong loops do not cover): sub-piece times, see conv3d_mfma.h. A stamp costs ~40 clocks and its lgkmcnt(0) also waits for the
-wave's in-flight prefetch reads: instrumented builds run 10-25 % slower and shift time between neighbouring columns.
+-DSN_TIMING=1..4 (the one-wave-per-SIMD loop, i.e. merge_conv_a/b): the two columns hold 1: {burst A, burst B}, 2: {vmcnt wait, barrier}, 3: {burst M,
+whole piece} per piece, 4: per slab {slab head, piece loop}; "pieces" counts what the mode counts. -DSN_TIMING=10 (every conv kernel): per TILE {store
+epilogue, K loop}. (The per-segment modes of the ping-pong loops and the sub-piece modes of the round-2 loop were removed with the round-5 pruning; their
+results are in profiles/r2 .. r4/README.md.) A stamp costs ~40 clocks and its lgkmcnt(0) also waits for the wave's in-flight prefetch reads:
+instrumented builds run 10-25 % slower and shift time between neighbouring columns.
 --simil: the similarityNet's layers instead of the SurfaceNet's."""
 import ctypes
 import os
