@@ -22,8 +22,8 @@ from those codes, already differs in 2.9 % of its fp16 values and 11 % of its lo
 the device's error, correlation 0.82 between the two error fields) is this sensitivity, not a modelling gap: every parameter variant
 tried (premultipliers, lo exponent, block shape, renormalisation on / off) lowers the correlation.
 mode "f16x3" (the default): everything "x3" except the concat buffer and merge_conv_a's output (storage m6, premultipliers s = 2 / 0)
-and merge_conv_a / merge_conv_b (product m6) and - round 5 - the dilated chain conv4_1 .. conv4_3 (product m6 on code planes with s = -1; conv3_3's
-code plane is derived from its stored hi / lo planes); conv1_3 / conv2_3 feed their side conv and pool from unrounded registers.
+and merge_conv_a / merge_conv_b (product m6) and - round 5 - conv4_2 / conv4_3 (product m6 on code planes with s = -2: conv4_1's and conv4_2's outputs);
+conv1_3 / conv2_3 feed their side conv and pool from unrounded registers.
 mode "f16m8": every tensor m6, every conv product m6 (the network input with s = -5).
 Round 5: a per-layer CORRECTION-FORMAT TABLE for the default mode (`table`, layer name -> "x3" | "m6" | "m8"; LAYER_FORMATS_DEFAULT is what
 the library ships) answers "which 3x3x3 layers may leave the three-fp16-MFMA arithmetic at an unchanged tolerance" without a GPU:
@@ -43,8 +43,9 @@ S8_ACT = 0
 LAYER_FORMATS_DEFAULT = {"conv1_1": "x3", "conv1_2": "x3", "conv1_3": "x3", "conv2_1": "x3", "conv2_2": "x3", "conv2_3": "x3",
                          "conv3_1": "x3", "conv3_2": "x3", "conv3_3": "x3", "conv4_1": "x3", "conv4_2": "x3", "conv4_3": "x3",
                          "merge_conv_a": "m6", "merge_conv_b": "m6"}
-S_C4 = -1                    # premultiplier of the code planes the conv4 chain reads when it runs on the fp6 MX step (conv3_3's, conv4_1's, conv4_2's outputs;
-S6_OF_DEFAULT = {"conv3_3": S_C4, "conv4_1": S_C4, "conv4_2": S_C4}      # mx_format.h SN_MX_S_C4): applies to table entries conv4_x = "m6" / "b6" only
+LAYER_FORMATS_R4 = dict(LAYER_FORMATS_DEFAULT)      # rounds 2-4: only the merge layers on the MX step
+S_C4 = -2                    # premultiplier of the code planes conv4_2 / conv4_3 read (conv4_1's and conv4_2's outputs; mx_format.h SN_MX_S_C4)
+S6_OF_DEFAULT = {"conv3_3": S_C4, "conv4_1": S_C4, "conv4_2": S_C4}      # (conv3_3's: for what-if tables that put conv4_1 on an MX format as well)
 
 
 def _ilogb(a):
@@ -211,9 +212,7 @@ def forward_emulated(X, values, w=None, n_vp=1, mode="f16x3", table=None, s8_act
             m = np.maximum(np.abs(p["gamma"].astype(np.float64)), np.abs(p["beta"].astype(np.float64)))
             oe = np.clip(-_ilogb(m), -60, 60).astype(np.float64)
             oe[~(m > 0)] = 0
-        # s6_of: what-if premultipliers of a layer's OUTPUT tensor (fp6 readers). conv3_3's code plane is derived from its stored (hi, lo) fp16 planes
-        # (x3_to_m6_kernel: side_op3 reads those), every other code plane straight from the fp32 result
-        return T(y, oe, s6_tab.get(name, s6_out), via16=(name == "conv3_3" and not full and fmt_of["conv4_1"] != "x3"))
+        return T(y, oe, s6_tab.get(name, s6_out))       # s6_tab: premultiplier of a layer's OUTPUT tensor as its fp6 readers see it
 
     def up(x, name, f):
         k = P[name]["W"].shape[2]

@@ -283,7 +283,10 @@ struct ConvCfg {
     // one wave per SIMD (conv3d_f16_mfma, PWM loop): 4 waves x (8 voxel x NF cout) fragments, accumulators in AGPRs; the tap tables of ALL slabs
     // (x both halo buffers) are written once per launch instead of once per slab
     static constexpr bool PWM = SPLIT == 2 && K2D == 0 && NW_ == 4 && KS == 3 && MF == 8 && SN_MX_FMT != 0 && PCH_ == 2;
-    static constexpr int PW_SLABS = 16;                    // most channel slabs a PWM layer may have (launch_conv checks)
+    // tap tables of the one-wave-per-SIMD loop, written once per launch: a slab's table depends only on the halo buffer it sits in, on its first unit (bridge
+    // pieces: 27 units per slab against 8 per piece - a function of slab mod 8) and on whether it is the tile's last: 16 tables per buffer, any number of slabs
+    static constexpr int PW_TABS = 16;
+    static constexpr int pw_tab(int kb, int slab, bool last) { return kb * PW_TABS + (last ? 8 : 0) + (slab & 7); }
     // LDS distance of voxel fragment m from fragment 0 of the same lane under the row-gap-4 map (frag_xyz: hx = wave * XS + (m >> 2), hy = (m & 3) + 4 (v >> 3)):
     // a compile-time constant, so the PWM loop addresses all fragments as one per-lane register + the read's immediate offset
     static constexpr int pw_xoff(int m) { return (((m >> 2) * HY + (m & 3)) * HZ) * VS; }
@@ -293,8 +296,9 @@ struct ConvCfg {
     // f16x3 3x3(x3) kernels on the ping-pong loop (PTAB): a slab's tap table depends only on the halo buffer it sits in, on its first unit (a function of
     // slab mod 4 with bridge chunks: 27 or 18 units per slab, 4 per chunk) and on whether it is the tile's last (b = 0, possibly fewer groups) - 8 tables per buffer, written once per launch instead of once per slab in a load slot
     static constexpr bool PTAB = SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && (K2D == 0 || SPLIT != 0) && !PWM;      // (= the kernels of the f16 / f16x3 ping-pong loop, 3-D and 2-D)
-    static constexpr int KTAB_N = PWM ? PW_SLABS * KOFF_N : (PTAB ? 8 * KOFF_N : KOFF_N);   // ints per halo buffer
-    static constexpr int NSEG = (HVOX * VS + 1023) / 1024; // 1 KiB DMA segments per plane
+    static constexpr int KTAB_N = PWM ? PW_TABS * KOFF_N : (PTAB ? 8 * KOFF_N : KOFF_N);   // ints per halo buffer
+    static constexpr int NSEG0 = (HVOX * VS + 1023) / 1024;
+    static constexpr int NSEG = PWM ? (NSEG0 + NW_ - 1) / NW_ * NW_ : NSEG0;   // 1 KiB DMA segments per plane (one-wave-per-SIMD loop: the same number for every wave)
     static constexpr int XPLANE = NSEG * 1024;
     static constexpr int XBUF = XPLANE * NPL;
     static constexpr bool CST_LDS = (EPI == EPI_STORE) && NF >= 7;   // wide store epilogues: keep scale/shift in LDS so the compiler's vmcnt(0) before their use cannot serialise the stores (measured: merge_conv_a -4 %, narrower layers +3..6 % -> off there)
@@ -328,7 +332,7 @@ conv3d_f16_mfma(ConvArgs a)
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     char *const xbuf = lds;                                   // [2][NPL][XPLANE]
     char *const wbuf = lds + 2 * C::XBUF;                     // [2][WBUF]
-    int *const kbuf = reinterpret_cast<int *>(lds + 2 * C::XBUF + 2 * C::WBUF);   // [2][KOFF_N]  (PWM: [2][PW_SLABS][KOFF_N])
+    int *const kbuf = reinterpret_cast<int *>(lds + 2 * C::XBUF + 2 * C::WBUF);   // [2][KOFF_N]  (PWM: [2][PW_TABS][KOFF_N])
     // epilogue constants live in LDS: a global load in the epilogue would make hipcc wait vmcnt(0), i.e. for every store
     // issued before it (measured: 21 us per tile of serialised store->load round trips in merge_conv_a)
     float *const cst = reinterpret_cast<float *>(lds + 2 * C::XBUF + 2 * C::WBUF + 2 * C::KTAB_N * 4);   // [2][NF*16]
@@ -520,7 +524,7 @@ conv3d_f16_mfma(ConvArgs a)
     auto write_koff_part = [&](int c8n, int kb, int slab, int t0, int nt) {
         int uo, ub;
         const int own = slab_units(c8n, slab, uo, ub) - ub, nchunk = (own + ub + 3) >> 2;
-        int *k = kbuf + (PWM ? kb * C::PW_SLABS + slab : (C::PTAB ? kb * 8 + ((slab + 1 == a.nslab) ? 4 : 0) + (slab & 3) : kb)) * C::KOFF_N;
+        int *k = kbuf + (PWM ? C::pw_tab(kb, slab, slab + 1 == a.nslab) : (C::PTAB ? kb * 8 + ((slab + 1 == a.nslab) ? 4 : 0) + (slab & 3) : kb)) * C::KOFF_N;
         for (int g = t0; g < (nchunk + 4) * 4; g += nt) {
             int o = 0;
             if (g < own + ub) {
@@ -595,9 +599,10 @@ conv3d_f16_mfma(ConvArgs a)
                 for (int sl = 0; sl < a.nslab; ++sl)
                     if (sl < 4 || sl + 1 == a.nslab) write_koff(slab_c8_of(sl), kb, sl);
         } else
-        if constexpr (PWM) {      // every slab's tap table, for either halo buffer it may land in (the bridge entries depend on the buffer)
+        if constexpr (PWM) {      // the 16 tables per halo buffer (ConvCfg::pw_tab; the bridge entries depend on the buffer): slabs 0..7 as representatives, the last slab
             for (int kb = 0; kb < 2; ++kb)
-                for (int sl = 0; sl < a.nslab; ++sl) write_koff(slab_c8_of(sl), kb, sl);
+                for (int sl = 0; sl < a.nslab; ++sl)
+                    if (sl < 8 || sl + 1 == a.nslab) write_koff(slab_c8_of(sl), kb, sl);
         } else
         write_koff(c8n, 0, 0);
         const int nch = wchunks_of(c8n, 0);
@@ -661,14 +666,14 @@ conv3d_f16_mfma(ConvArgs a)
         int pw_koB = 0;
         long long pw_k2 = 0;
         if constexpr (PWM) {
-            const unsigned tab0 = kbuf_a + (unsigned)((xb * C::PW_SLABS) * (C::KOFF_N * 4));
+            const unsigned tab0 = kbuf_a + (unsigned)(C::pw_tab(xb, 0, a.nslab == 1) * (C::KOFF_N * 4));
             int koA;
             lds_read32<0>(koA, tab0);
             lds_read32<16>(pw_koB, tab0);
             lds_read64<0>(pw_k2, tab0 + kq * 4);
             lgkm_wait<0>();
             const unsigned xa = xbuf_a + xb * C::XBUF + (unsigned)xbase[0] + (unsigned)koA, wp0 = wbuf_a + wbi * C::WBUF;
-            static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<C::pw_xoff(m)>(pw_xf[m], xa); });
+            static_for<0, MF>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<C::xoff_of(m)>(pw_xf[m], xa); });
             static_for<0, NF>([&](auto nc) { constexpr int n = decltype(nc)::value; lds_read128<n * 1024>(pw_wf[n], wp0); });
             lgkm_wait<0>();
         }
@@ -715,15 +720,17 @@ conv3d_f16_mfma(ConvArgs a)
                 // burst: by then every wave has read all it needs from the piece's weight buffer (so the piece after next may be fetched into
                 // it) and its share of the next piece's DMAs has landed (the MX burst reads the next piece's first fragments).
                 // Same K order, same MFMAs per accumulator as the ping-pong loop: bit-identical results.
-                static_assert(SPLIT == 2 && C::PCH == 2 && BUFH && DIL == 1 && kRowGap3x3 == 4 && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0,
+                static_assert(SPLIT == 2 && C::PCH == 2 && BUFH && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0 && C::XPLANE + C::xoff_of(MF - 1) < 65536,
                               "one-wave-per-SIMD loop: f16m8 3x3x3 kernels");
                 long long pws1 = 0;                    // SN_TIMING 4: per slab {everything in front of the piece loop since the previous slab's last piece, the piece loop}
                 constexpr int mxo = 2 * NF * 1024;
                 constexpr int WCNT = C::PCH * NF * NPL, WPW = (WCNT + C::NW - 1) / C::NW;      // 1 KiB DMAs per weight piece / per wave
                 constexpr int NM = MF * NF;
-                static_assert(16 + 3 * (WPW + HT / 2 - 1) < NM && 4 + 2 * NF + 15 < NM, "filler schedule exceeds the burst");
-                const unsigned tab_a = kbuf_a + (unsigned)((xb * C::PW_SLABS + slab) * (C::KOFF_N * 4));
-                const unsigned ntab_a = kbuf_a + (unsigned)(((xb ^ 1) * C::PW_SLABS + nslab_i) * (C::KOFF_N * 4));
+                // burst A: behind its first 16 MFMAs (operand reads) one DMA slot every DSP MFMAs - the next weight piece's WPW and (a slab's first two pieces) HT / 2 halo DMAs
+                constexpr int DSP = (NM - 16) / (WPW + HT / 2) >= 3 ? 3 : 2;
+                static_assert(MF + NF <= 16 && 16 + DSP * (WPW + HT / 2 - 1) < NM && 4 + 2 * NF + 15 < NM, "filler schedule exceeds the burst");
+                const unsigned tab_a = kbuf_a + (unsigned)(C::pw_tab(xb, slab, last_slab) * (C::KOFF_N * 4));
+                const unsigned ntab_a = kbuf_a + (unsigned)(C::pw_tab(xb ^ 1, nslab_i, nlast) * (C::KOFF_N * 4));
                 const unsigned xs_a = xbuf_a + xb * C::XBUF + (unsigned)xbase[0];
                 const unsigned nxs_a = xbuf_a + (xb ^ 1) * C::XBUF + (unsigned)xbase[0];
                 // the halo tile staged during this slab's first two pieces: the next slab's / the next tile's first slab (carried pointers, see the tile loop)
@@ -776,16 +783,17 @@ conv3d_f16_mfma(ConvArgs a)
                         constexpr int i = decltype(ic)::value, n = i / MF, m = i % MF;
                         pw_mfma_f16(acc[m][n], pw_wf[n], pw_xf[m]);
                         if constexpr (i == 0) lds_read128<NF * 1024>(wfB[0], wp);
-                        else if constexpr (i <= MF) lds_read128<C::pw_xoff(i >= 1 && i <= MF ? i - 1 : 0)>(xfB[i >= 1 && i <= MF ? i - 1 : 0], kosB);
+                        else if constexpr (i <= MF) lds_read128<C::xoff_of(i >= 1 && i <= MF ? i - 1 : 0)>(xfB[i >= 1 && i <= MF ? i - 1 : 0], kosB);
                         else if constexpr (i < MF + NF) lds_read128<(NF + (i < MF + NF ? i - MF : 0)) * 1024>(wfB[i < MF + NF ? i - MF : 0], wp);
-                        else if constexpr (i >= 16 && (i - 16) % 3 == 0 && (i - 16) / 3 < WPW + HH) {
-                            constexpr int q = (i - 16) / 3;                  // DMA slot q of the burst: weights and halo segments alternate while both last
-                            constexpr bool is_h = (q % 2 == 1) && (q / 2 < HH);
+                        else if constexpr (i >= 16 && (i - 16) % DSP == 0 && (i - 16) / DSP < WPW + HH) {
+                            constexpr int q = (i - 16) / DSP;                // DMA slot q of the burst: weights and halo segments alternate while both last
+                            constexpr int MN = WPW < HH ? WPW : HH;
+                            constexpr bool is_h = q < 2 * MN ? (q % 2 == 1) : (HH > WPW);
                             if constexpr (!is_h) {
-                                constexpr int k = q < 2 * HH ? q / 2 : q - HH;      // this wave's k-th KiB of the next weight piece
+                                constexpr int k = q < 2 * MN ? q / 2 : q - HH;      // this wave's k-th KiB of the next weight piece
                                 dma16_s(wsrc, pw_wv + k * (C::NW * 1024), wdst_a + k * (C::NW * 1024));
                             } else {
-                                constexpr int j = q / 2;
+                                constexpr int j = q < 2 * MN ? q / 2 : q - WPW;
                                 if (halo_now) {
                                     const unsigned hw = first ? hword[j] : hword[HH + j];
                                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(hdst_p + (unsigned)(j * C::NW * 1024)),
@@ -818,7 +826,7 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (i == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
                         else if constexpr (i <= 4) {
                             constexpr int mm = (i - 1) / 2, sl = (i - 1) & 1;
-                            lds_read128i<C::XPLANE + C::pw_xoff(mm)>(x8h[mm][sl], sl ? ks1 : ks0);
+                            lds_read128i<C::XPLANE + C::xoff_of(mm)>(x8h[mm][sl], sl ? ks1 : ks0);
                         } else if constexpr (i <= RB) {
                             constexpr int j = i - 5, nn = j / 2;
                             if constexpr (j & 1) lds_read64<mxo + nn * 2048 + 1024>(wb2[nn], wp);
@@ -855,26 +863,31 @@ conv3d_f16_mfma(ConvArgs a)
                     int wsc_lo = (int)wsc, wsc_hi = (int)(wsc >> 32);
                     asm volatile("s_nop 3" : "+v"(wsc_lo), "+v"(wsc_hi));      // (VALU moves that formed the operands above -> first MFMA: the hazard is not visible to hipcc)
                     const unsigned kosA = nx_a + (unsigned)koA_n;
-                    static_assert(NF >= 7 && HT <= MF, "MX burst: 7 filler slots per voxel fragment");
+                    // filler slots behind MFMA n of voxel-fragment group m: n = 0, 1 the code slots of fragment m + 2; then - NF >= 7 - n = 2, 3 two next-A reads and
+                    // n = 4 the operand of fragment m + 1, or - NF = 5, 6 - n = 2 the operand of fragment m + 1 (two MFMAs ahead of its first use: the hazard
+                    // between a VALU write and an inline-asm MFMA is ours to keep) and n = 3, 4 the next-A reads
+                    static_assert(NF >= 5, "MX burst: 5 filler slots per voxel fragment");
+                    constexpr int NA_N0 = NF >= 7 ? 2 : 3, FORM_N = NF >= 7 ? 4 : 2;
+                    auto valid_na = [](int g) constexpr { return g < 0 ? 0 : (2 * g < MF + NF ? 1 : 0) + (2 * g + 1 < MF + NF ? 1 : 0); };
                     // next-A read r = 0 .. MF + NF - 1: weight fragment 0, the MF activation fragments, weight fragments 1 .. NF - 1
                     auto next_a = [&](auto rc) {
                         constexpr int r = decltype(rc)::value;
                         if constexpr (r == 0) lds_read128<0>(pw_wf[0], wpn);            // (straight into the carried registers: chunk 2p is long done with them)
-                        else if constexpr (r <= MF) lds_read128<C::pw_xoff(r - 1)>(pw_xf[r - 1], kosA);
+                        else if constexpr (r <= MF) lds_read128<C::xoff_of(r - 1)>(pw_xf[r - 1], kosA);
                         else if constexpr (r < MF + NF) lds_read128<(r - MF) * 1024>(pw_wf[r - MF], wpn);
                     };
                     static_for<0, NM>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, m = i / NF, n = i % NF;
                         pw_mfma_mx6<(n & 3)>(acc[m][n], wa[n], x8[m], n < 4 ? wsc_lo : wsc_hi, mx_sb);
-                        if constexpr (n == 0) { if constexpr (m + 2 < MF) lds_read128i<C::XPLANE + C::pw_xoff(m + 2 < MF ? m + 2 : 0)>(x8h[m + 2 < MF ? m + 2 : 0][0], ks0); }
-                        else if constexpr (n == 1) { if constexpr (m + 2 < MF) lds_read128i<C::XPLANE + C::pw_xoff(m + 2 < MF ? m + 2 : 0)>(x8h[m + 2 < MF ? m + 2 : 0][1], ks1); }
-                        else if constexpr (n == 2) next_a(IntC<2 * m>{});
-                        else if constexpr (n == 3) next_a(IntC<2 * m + 1>{});
-                        else if constexpr (n == 4) {
+                        if constexpr (n == 0) { if constexpr (m + 2 < MF) lds_read128i<C::XPLANE + C::xoff_of(m + 2 < MF ? m + 2 : 0)>(x8h[m + 2 < MF ? m + 2 : 0][0], ks0); }
+                        else if constexpr (n == 1) { if constexpr (m + 2 < MF) lds_read128i<C::XPLANE + C::xoff_of(m + 2 < MF ? m + 2 : 0)>(x8h[m + 2 < MF ? m + 2 : 0][1], ks1); }
+                        else if constexpr (n == NA_N0) next_a(IntC<2 * m>{});
+                        else if constexpr (n == NA_N0 + 1) next_a(IntC<2 * m + 1>{});
+                        else if constexpr (n == FORM_N) {
                             if constexpr (m + 1 < MF) {
-                                // slots of fragment m + 1: read in burst B (m = 0) or behind group m - 1; younger reads: that group's two next-A reads
-                                // and this group's (up to) four
-                                if constexpr (m >= 1) lgkm_wait<2 + (m + 2 < MF ? 4 : 2)>();
+                                // slots of fragment m + 1: read in burst B (m = 0) or behind group m - 1; younger reads: that group's next-A reads, this group's
+                                // two slot reads and - where they come first - its next-A reads
+                                if constexpr (m >= 1) lgkm_wait<valid_na(m - 1) + (m + 2 < MF ? 2 : 0) + (FORM_N > NA_N0 ? valid_na(m) : 0)>();
                                 form_x8(IntC<(m + 1 < MF ? m + 1 : 0)>{});
                             }
                         }

@@ -241,32 +241,6 @@ __global__ void __launch_bounds__(256) upsample3_cat_tiled_kernel(const _Float16
     }
 }
 
-// (hi, lo) fp16 planes -> the 16-byte code slots of the f16m8 storage format (mx_format.h), for a tensor with TWO kinds of readers: conv3_3's output
-// feeds side_op3 (three-fp16-MFMA arithmetic: hi + lo planes) and conv4_1 (f16m8 arithmetic: hi plane + code plane). One thread per 8-channel group.
-// A value beyond the code range raises the layer's WARNING bit (ConvArgs::mx_sat_bits' counterpart for this plane).
-static __global__ void __launch_bounds__(256) x3_to_m6_kernel(const _Float16 *hi, long long lo_off, uint4 *codes, long long groups, int e8, unsigned sat_bits,
-                                                              unsigned *status, unsigned status_bit)
-{
-#if SN_MX_FMT != 0
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    bool sat = false;
-    if (i < groups) {
-        const h8 h = *reinterpret_cast<const h8 *>(hi + i * 8), l = *reinterpret_cast<const h8 *>(hi + i * 8 + lo_off);
-        mx_v32h t = {};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            t[e] = h[e]; t[4 + e] = (_Float16)((float)l[e] * kMxLoMul);
-            t[8 + e] = h[4 + e]; t[12 + e] = (_Float16)((float)l[4 + e] * kMxLoMul);
-        }
-        const mx_v6i c = sn_mx6_cvt(t, e8);
-        codes[i] = uint4{(unsigned)c[0], (unsigned)c[1], (unsigned)c[2], 0u};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sat |= (unsigned)(__builtin_bit_cast(unsigned short, h[e]) & 0x7fffu) > sat_bits;
-    }
-    if (status && sat_bits && __builtin_amdgcn_ballot_w64(sat) != 0 && (threadIdx.x & 63) == 0) atomicOr(status + 1, status_bit);
-#endif
-}
-
 // Calibration scan (sn_calibrate_dev): how many of a tensor's stored fp16 values exceed the range of 6-bit codes under each candidate premultiplier.
 // hist[j], j = 0 .. kMxScanBins - 1: count of |v| > lim * 2^-(j - kMxScanBins / 2), lim = the code format's largest magnitude; hist[kMxScanBins] = count of
 // non-zero values, hist[kMxScanBins + 1] = fp16 bits of the largest magnitude. `halfs` is a multiple of 8 (8-channel groups).

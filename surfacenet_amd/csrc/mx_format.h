@@ -32,8 +32,8 @@ constexpr float kMxLoMul = (float)(1 << kMxLoExp);
 #define SN_MX_S_CAT 2
 #endif
 #ifndef SN_MX_S_C4
-#define SN_MX_S_C4 (-1)     // conv3_3's output and the conv4 chain (default mode, round 5): ReLU outputs with a heavier tail than merge_conv_a's - under s = 0 the
-#endif                      // saturated codes put the modelled L_inf at 1.5e-4 .. 2.8e-4, under s = -1 (range 15) at 9e-5 .. 1.1e-4 (oracle/net_emulation.py, tools/format_table.py)
+#define SN_MX_S_C4 (-2)     // conv4_1's and conv4_2's outputs (default mode, round 5: conv4_2 / conv4_3 on the MX step): ReLU outputs whose tail real pixels stretch far beyond what
+#endif                      // noise inputs show - modelled L_inf on real DTU / dino pixels 4.2e-4 under s = -1, 1.3e-4 under s = -2 (range 30), 1.4e-4 .. 1.7e-4 under s = -3 (tools/format_table.py)
 constexpr int kMxActE8 = SN_MX_FMT ? 127 - SN_MX_S_ACT : 127;
 constexpr int kMxC4E8 = SN_MX_FMT ? 127 - (SN_MX_S_C4) : 127;
 constexpr int kMxCatE8 = SN_MX_FMT ? 127 - SN_MX_S_CAT : 127;

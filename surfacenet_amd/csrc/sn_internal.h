@@ -101,9 +101,8 @@ struct sn_ctx {
     bool have_weights = false, have_relw = false;
     int split = 1;              // 0: f16 operands; 1: f16x3 (hi/lo split operands, fp32-class results) — default; 2: f16m8
     int mode = 1;               // the SN_PRECISION_* value given to sn_set_precision
-    int mx_c4_e8 = kMxC4E8;     // ... of conv3_3's output (code plane a3c) and of the conv4 chain's tensors when conv4_x runs in the f16m8 arithmetic (c4_m6)
-    bool c4_m6 = false;         // EXPERIMENT (off), round 5: conv4_1 .. conv4_3 with their correction terms on the 6-bit MX MFMA (1.5 MFMA units per product instead of 3)
-    _Float16 *a3c = nullptr;    // code plane of conv3_3's output (x3_to_m6_kernel), [max_samples][160/8][D/4]^3 slots of 16 bytes
+    int mx_c4_e8 = kMxC4E8;     // ... of conv4_1's and conv4_2's outputs when conv4_2 / conv4_3 run in the f16m8 arithmetic (c4_m6)
+    bool c4_m6 = false;         // experiment (off): conv4_2 / conv4_3 with their correction terms on the 6-bit MX MFMA (sn_set_precision)
     int mx_act_e8 = kMxActE8, mx_cat_e8 = kMxCatE8;   // mx_format.h; SN_MX_S_ACT / SN_MX_S_CAT in the environment override them in the default (hybrid) mode
     int tail_m8 = 2;            // f16x3: 2 = merge_conv_a + merge_conv_b run their two correction terms on the MX MFMA (the default), 0 = none (f16x3p)
     bool ws_ready = false; int ws_split = -1;
@@ -277,7 +276,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     {
         // static premultipliers of the 6-bit code planes (mx_format.h): the concat buffer holds sigmoid outputs, everything else ReLU(BN(.))
         auto e8_of = [&](const _Float16 *t) {
-            if (t && c->c4_m6 && (t == c->a3 || t == c->a4 || t == c->b4)) return c->mx_c4_e8;
+            if (t && c->c4_m6 && c->split == 1 && (t == c->a4 || t == c->b4)) return c->mx_c4_e8;
             return t && t == c->cat ? c->mx_cat_e8 : (t && t == c->x0 ? kMxX0E8 : c->mx_act_e8);
         };
         a.mx_in_e8 = e8_of(in.p); a.mx_out_e8 = e8_of(out.p); a.mx_side_e8 = sf ? e8_of(sf->side_out.p) : c->mx_act_e8;
@@ -308,8 +307,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     a.bridge = L.bridge;
     if (L.bridge && !sn::sn_conv_has_bridge<KS, SPLIT, NW, PCH, NF, K2D, MF>())
         return fail(SN_ERR_STATE, "%s: packed with bridge chunks, launched on a kernel without them", L.name.c_str());
-    if (C::PWM) {      // one-wave-per-SIMD loop: all tap tables live in LDS; a slab's first piece issues DMAs that its second piece waits for
-        if (a.nslab > C::PW_SLABS) return fail(SN_ERR_STATE, "%s: %d channel slabs exceed the %d this kernel keeps tap tables for", L.name.c_str(), a.nslab, C::PW_SLABS);
+    if (C::PWM) {      // one-wave-per-SIMD loop: a slab's first piece issues DMAs that its second piece waits for
         for (unsigned char c8n : L.slab_c8)
             if (C::NTAP * c8n < 9) return fail(SN_ERR_STATE, "%s: a channel slab of fewer than two weight pieces", L.name.c_str());
     }
