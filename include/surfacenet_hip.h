@@ -218,9 +218,9 @@ SN_API int sn_project_points(sn_ctx *ctx, int V, const double *P, int n, const d
                       double *img_w, double *depth);
 
 /* ---- numerics of the default mode's 6-bit code planes ------------------------------------------------------------
- * The two merge layers - and, since round 5, the dilated layers conv4_1 .. conv4_3 - read their inputs as fp16 + 6-bit e2m3 codes scaled by a
- * per-tensor premultiplier 2^s ("cat": the concat buffer of sigmoid side outputs; "act": merge_conv_a's ReLU output; "c4": conv3_3's output and the
- * conv4 chain). s is static - sized from the layers' BatchNorm parameters, which trained nets obey
+ * The two merge layers read their inputs as fp16 + 6-bit e2m3 codes scaled by a per-tensor premultiplier 2^s ("cat": the concat buffer of
+ * sigmoid side outputs; "act": merge_conv_a's ReLU output). (The dilated layers conv4_1 .. conv4_3 run the same two-term correction on fp8 e4m3
+ * codes since round 5: those have the exponent range, there is nothing to calibrate.) s is static - sized from the layers' BatchNorm parameters, which trained nets obey
  * (nets/SurfaceNet.py:33-74, every batch_norm) - unless the caller calibrates it on data:
  *   sn_calibrate_dev looks at the activations the LAST forward call left in the workspace (n_samples of them, <= 0: all that call ran; run
  *   sn_forward / sn_cvc_forward on a representative batch first - SN_ERR_STATE when none has run since the weights / the mode were set, or when it
@@ -233,10 +233,6 @@ typedef struct sn_calibration {
     int s_act_before, s_cat_before, s_act, s_cat;                /* premultiplier exponents before / after */
     double sat_act_before, sat_cat_before, sat_act, sat_cat;     /* saturated fraction of the non-zero values under them */
     float max_act, max_cat;                                      /* largest stored magnitude */
-    /* round 5: "c4" = conv3_3's output and the dilated chain conv4_1 .. conv4_3, which the default mode also runs in this arithmetic (static s = -1) */
-    int s_c4_before, s_c4;
-    double sat_c4_before, sat_c4;
-    float max_c4;
 } sn_calibration;
 SN_API int sn_calibrate_dev(sn_ctx *ctx, int n_samples, double max_sat_fraction, sn_calibration *out);
 SN_API int sn_numeric_status(sn_ctx *ctx, unsigned *saturated_bits, char *names, int names_cap);

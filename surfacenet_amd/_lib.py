@@ -39,8 +39,7 @@ class SparseCfg(ctypes.Structure):
 class Calibration(ctypes.Structure):
     _fields_ = [("s_act_before", ctypes.c_int), ("s_cat_before", ctypes.c_int), ("s_act", ctypes.c_int), ("s_cat", ctypes.c_int),
                 ("sat_act_before", ctypes.c_double), ("sat_cat_before", ctypes.c_double), ("sat_act", ctypes.c_double), ("sat_cat", ctypes.c_double),
-                ("max_act", ctypes.c_float), ("max_cat", ctypes.c_float),
-                ("s_c4_before", ctypes.c_int), ("s_c4", ctypes.c_int), ("sat_c4_before", ctypes.c_double), ("sat_c4", ctypes.c_double), ("max_c4", ctypes.c_float)]
+                ("max_act", ctypes.c_float), ("max_cat", ctypes.c_float)]
 
 
 class ParamDesc(ctypes.Structure):

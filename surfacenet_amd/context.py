@@ -54,18 +54,17 @@ class NumericsGuard(object):
         # merge_conv_a's outputs (measured: 0.1 .. 0.3 % on uncalibrated random nets, 0.22 % on the worst structured input - L_inf unchanged at 5e-5);
         # the guard acts when more than `trigger_fraction` (1 %) of a plane's non-zero values saturate (x3.2 stress net: 5 %, L_inf 2e-4).
         probe = self.ctx.calibrate(0, -1.0)
-        if max(probe["sat_act_before"], probe["sat_cat_before"], probe["sat_c4_before"]) < self.trigger_fraction:
+        if max(probe["sat_act_before"], probe["sat_cat_before"]) < self.trigger_fraction:
             self.calibrated = False              # nothing to redo, nothing to report - the watch goes on
             return None
         cal = self.ctx.calibrate(0, self.max_sat_fraction)
         self.report = cal
         warnings.warn("surfacenet_amd (%s): stored activations of %s exceeded the range of their 6-bit code planes (%.2f %% of merge_conv_a's non-zero "
                       "outputs, %.2f %% of the concat buffer; the network's BatchNorm statistics under-estimate their spread). Premultipliers "
-                      "recalibrated on this batch: s_act %d -> %d, s_cat %d -> %d, s_c4 %d -> %d (saturated fraction now %.3f %% / %.3f %% / %.3f %%); the "
-                      "batch is recomputed. Pass auto_calibrate=False to keep the static exponents."
+                      "recalibrated on this batch: s_act %d -> %d, s_cat %d -> %d (saturated fraction now %.3f %% / %.3f %%); the batch is recomputed. "
+                      "Pass auto_calibrate=False to keep the static exponents."
                       % (where, ", ".join(names), 100 * cal["sat_act_before"], 100 * cal["sat_cat_before"], cal["s_act_before"], cal["s_act"],
-                         cal["s_cat_before"], cal["s_cat"], cal["s_c4_before"], cal["s_c4"], 100 * cal["sat_act"], 100 * cal["sat_cat"], 100 * cal["sat_c4"]),
-                      RuntimeWarning, stacklevel=3)
+                         cal["s_cat_before"], cal["s_cat"], 100 * cal["sat_act"], 100 * cal["sat_cat"]), RuntimeWarning, stacklevel=3)
         return cal
 
 

@@ -22,6 +22,9 @@
 //                     v_mfma_scale_f32_16x16x128_f8f6f4 per 64 k (fp8 e4m3 operands, lo parts pre-scaled by 2^12, the
 //                     2^-12 applied through the E8M0 block scale): 2 MFMA units per product instead of 3. L_inf vs the
 //                     fp64 oracle ~1e-4 (bar 1e-3). Second activation plane = [fp8(hi) x8 | fp8(lo*2^12) x8] per group.
+//   SPLIT=3  "f16m8e" (round 5; the dilated layers conv4_x of the default mode): the same with fp8 e4m3 codes - 2 MFMA units per product, and the EXPONENT RANGE
+//                     the 6-bit codes lack: a static 6-bit premultiplier cannot hold the data-dependent outliers of the conv4 chain (profiles/r5/README.md).
+//                     Second activation plane = [fp8(hi * 2^s) x8 | fp8(lo * 2^12 * 2^s) x8] per group; weights as plain fp8 codes (no block scales).
 // GEMM view: D[cout][voxel] += W[cout][k] * X[k][voxel], k = (tap, cin) in 8-channel groups.
 //   A operand = weights, pre-packed on the host in fragment order (lane l: cout = l&15, k = (l>>4)*8 + j);
 //   B operand = activations of a (TX+2R)x(TY+2R)x(TZ+2R) halo tile, staged per channel slab in LDS and re-read
@@ -92,6 +95,7 @@ struct ConvArgs {
     float scale3, shift3;
     long long wsplit_stride;  // halfs between channel splits in wpack
     long long in_lo_off, out_lo_off;
+    long long out_code_off;   // OSPLIT 4 (hi + lo + fp8 code slots: a tensor with readers of both kinds): the slot plane, in halfs from `out`
     int in_cs, out_cs, out_coff, out_cp;
     int D, DX, tiles_x, tiles_y, tiles_z, total_tiles;   // volume = DX x D x D voxels (3-D nets: DX = D; 2-D nets: x = image index)
     int act;              // 0 relu, 1 sigmoid
@@ -252,6 +256,11 @@ __device__ __forceinline__ void pw_mfma_mx6(f32x4 &c, const mx_v6i &a, const mx_
     else asm volatile(SN_MX6_ASM("op_sel:[1,0,0] op_sel_hi:[1,0,0]") : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 #undef SN_MX6_ASM
 }
+// The same on fp8 e4m3 operands (256 bits per lane); sa, sb: E8M0 scales of the weight / activation side in byte 0
+__device__ __forceinline__ void pw_mfma_mx8(f32x4 &c, const v8i &a, const v8i &b, int sa, int sb)
+{
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
 // Halo-voxel validity bits kept in the top bits of a lane's precomputed halo offset (see stage_halo_buf): a set bit that applies to
 // the tile at hand stays in the offset and pushes it out of the descriptor's range.
 constexpr unsigned HB_ALWAYS = 1u << 31, HB_XLO = 1u << 30, HB_XHI = 1u << 29, HB_YLO = 1u << 28, HB_YHI = 1u << 27, HB_ZLO = 1u << 26,
@@ -276,13 +285,14 @@ struct ConvCfg {
     static constexpr int NPLM = SPLIT == 1 ? 2 : 1;        // planes the f16 main loop reads (f16x3: hi and lo)
     static constexpr int FRAG = 1024 * NPL;                // weight bytes per (K-chunk, cout fragment)
     static constexpr int MFRAG = 1024 * NPLM;              // bytes of one f16 weight fragment set (hi [+ lo])
-    static_assert(SPLIT != 2 || PCH_ == 2, "f16m8: a weight piece is 2 K-chunks + one MX step");
+    static_assert(SPLIT < 2 || PCH_ == 2, "f16m8: a weight piece is 2 K-chunks + one MX step");
+    static constexpr int MXF = SPLIT == 3 ? 0 : SN_MX_FMT; // code format of the MX step: 0 fp8 e4m3 (SPLIT 3), else the 6-bit form of mx_format.h
     static constexpr int WBUF = PCH * NF * FRAG;
     static constexpr int NTAP = (K2D ? 1 : KS) * KS * KS;
     static constexpr int KOFF_N = NTAP * CS8MAX + 24;      // + look-ahead padding (2 chunks; f16m8: one 8-group piece; bridged slabs: up to 7 units of the next slab)
     // one wave per SIMD (conv3d_f16_mfma, PWM loop): 4 waves x (8 voxel x NF cout) fragments, accumulators in AGPRs; the tap tables of ALL slabs
     // (x both halo buffers) are written once per launch instead of once per slab
-    static constexpr bool PWM = SPLIT == 2 && K2D == 0 && NW_ == 4 && KS == 3 && MF == 8 && SN_MX_FMT != 0 && PCH_ == 2;
+    static constexpr bool PWM = (SPLIT == 3 || (SPLIT == 2 && SN_MX_FMT != 0)) && K2D == 0 && NW_ == 4 && KS == 3 && MF == 8 && PCH_ == 2;
     // tap tables of the one-wave-per-SIMD loop, written once per launch: a slab's table depends only on the halo buffer it sits in, on its first unit (bridge
     // pieces: 27 units per slab against 8 per piece - a function of slab mod 8) and on whether it is the tile's last: 16 tables per buffer, any number of slabs
     static constexpr int PW_TABS = 16;
@@ -295,7 +305,7 @@ struct ConvCfg {
     static constexpr int xoff_of(int m) { return XGAP == 4 ? pw_xoff(m) : (((m >> 2) * HY + (m & 1) + 4 * ((m >> 1) & 1)) * HZ) * VS; }
     // f16x3 3x3(x3) kernels on the ping-pong loop (PTAB): a slab's tap table depends only on the halo buffer it sits in, on its first unit (a function of
     // slab mod 4 with bridge chunks: 27 or 18 units per slab, 4 per chunk) and on whether it is the tile's last (b = 0, possibly fewer groups) - 8 tables per buffer, written once per launch instead of once per slab in a load slot
-    static constexpr bool PTAB = SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && (K2D == 0 || SPLIT != 0) && !PWM;      // (= the kernels of the f16 / f16x3 ping-pong loop, 3-D and 2-D)
+    static constexpr bool PTAB = SPLIT < 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && (K2D == 0 || SPLIT != 0) && !PWM;      // (= the kernels of the f16 / f16x3 ping-pong loop, 3-D and 2-D)
     static constexpr int KTAB_N = PWM ? PW_TABS * KOFF_N : (PTAB ? 8 * KOFF_N : KOFF_N);   // ints per halo buffer
     static constexpr int NSEG0 = (HVOX * VS + 1023) / 1024;
     static constexpr int NSEG = PWM ? (NSEG0 + NW_ - 1) / NW_ * NW_ : NSEG0;   // 1 KiB DMA segments per plane (one-wave-per-SIMD loop: the same number for every wave)
@@ -318,7 +328,7 @@ constexpr bool sn_conv_has_bridge()
 {
     return (SPLIT == 1 && NW == 8 && KS == 3 && PCH >= 2) ||
            (SPLIT == 2 && K2D == 0 && NW == 8 && KS == 3 && SN_MX_FMT != 0) ||
-           (SPLIT == 2 && K2D == 0 && NW == 4 && MF == 8 && KS == 3 && PCH == 2 && SN_MX_FMT != 0);
+           ((SPLIT == 3 || (SPLIT == 2 && SN_MX_FMT != 0)) && K2D == 0 && NW == 4 && MF == 8 && KS == 3 && PCH == 2);
 }
 
 // OSPLIT: storage format of the OUTPUT tensor (defaults to SPLIT): lets an f16x3 layer feed an f16m8 layer.
@@ -342,7 +352,7 @@ conv3d_f16_mfma(ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v = lane & 15, kq = lane >> 4;
     int mx_sb = a.mx_in_e8;                                  // scale operand of the MX step's activation side (6-bit forms): loaded once, kept in a VGPR
-    if constexpr (SPLIT == 2 && SN_MX_FMT != 0) asm volatile("" : "+v"(mx_sb));
+    if constexpr (SPLIT == 3 || (SPLIT == 2 && SN_MX_FMT != 0)) asm volatile("" : "+v"(mx_sb));
     const int D = a.D, DX = a.DX;
     const size_t VOL = (size_t)DX * D * D;
     const int tstride = gridDim.x;
@@ -405,7 +415,7 @@ conv3d_f16_mfma(ConvArgs a)
     // slab fits the offset field. The one-plane f16 mode of the 2-D nets (4-group slabs: up to 400 MB) keeps the generic path.
     constexpr bool BUFH = (K2D == 0) || (SPLIT != 0);
     constexpr bool PPM = SPLIT == 2 && K2D == 0 && NW_ == 8 && KS == 3 && SN_MX_FMT != 0;   // ping-pong K loop, f16m8 kernels (slab loop)
-    constexpr bool PPX = SPLIT != 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && BUFH;          // ... f16 / f16x3 kernels
+    constexpr bool PPX = SPLIT < 2 && NW_ == 8 && KS == 3 && PCH_ >= 2 && BUFH;          // ... f16 / f16x3 kernels
     constexpr bool PP = PPM || PPX;
     constexpr bool PWM = C::PWM;                   // one wave per SIMD (slab loop)
     constexpr bool UNI = PP || PWM;                // loops in which hipcc's divergence analysis loses wave-uniform values (stage_halo_buf)
@@ -502,7 +512,7 @@ conv3d_f16_mfma(ConvArgs a)
     // 4th with one chunk, three units and a full-size weight DMA. Bridged, merge_conv_a's 8 slabs are 27 pieces instead of 32 and merge_conv_b's
     // 13 are 44 instead of 52; the bridge piece is a slab's third or fourth, behind the vmcnt(0) of the second piece's MX load slot.
     constexpr bool BRIDGE_OK = (PPX && SPLIT == 1) || PPM || PWM;
-    constexpr int UM = SPLIT == 2 ? 8 : 4;                   // units per chunk / per piece: what a slab's unit count is rounded up to
+    constexpr int UM = SPLIT >= 2 ? 8 : 4;                   // units per chunk / per piece: what a slab's unit count is rounded up to
     constexpr int BSTEP = (UM - (C::NTAP * C::CS8MAX) % UM) % UM;      // bridged layers (all slabs hold CS8MAX groups): a slab starts this many units later (mod UM) than its predecessor
     const bool bridge = BRIDGE_OK && a.bridge != 0;
     // units of slab `slab` in its chunks: GU - o of its own (o: taken by the slab before) + b of the next slab's
@@ -517,7 +527,7 @@ conv3d_f16_mfma(ConvArgs a)
     };
     auto chunks_of = [&](int c8n, int slab) { int o, b; return (slab_units(c8n, slab, o, b) + 3) >> 2; };
     // K-chunks the weight STREAM holds for a slab (f16m8 pads every slab to whole pieces)
-    auto wchunks_of = [&](int c8n, int slab) { int o, b; return SPLIT == 2 ? (((slab_units(c8n, slab, o, b) + 7) >> 3) << 1) : chunks_of(c8n, slab); };
+    auto wchunks_of = [&](int c8n, int slab) { int o, b; return SPLIT >= 2 ? (((slab_units(c8n, slab, o, b) + 7) >> 3) << 1) : chunks_of(c8n, slab); };
     const int wchunk0 = wchunks_of(slab_c8_of(0), 0);        // ... of a tile's first slab
     // tap table of slab `slab` (c8n groups) into table buffer kb (= the halo buffer that holds the slab): entry g = LDS byte offset of
     // (tap, group) unit g's 16-byte slot relative to a voxel's own slot
@@ -686,7 +696,7 @@ conv3d_f16_mfma(ConvArgs a)
             // units of this slab's chunks / pieces: GU - o of its own (o: taken by the slab before) + b of the next slab's (slab_units, branch-free on the carried o)
             const int su_o = sl_o, su_b = (UM - ((C::NTAP * c8n - su_o) & (UM - 1))) & ((bridge && !last_slab) ? UM - 1 : 0);
             const int units = C::NTAP * c8n - su_o + su_b;
-            const int nchunk = (units + 3) >> 2, wchunk = SPLIT == 2 ? ((units + 7) >> 3) << 1 : nchunk;
+            const int nchunk = (units + 3) >> 2, wchunk = SPLIT >= 2 ? ((units + 7) >> 3) << 1 : nchunk;
             const int npiece = (nchunk + C::PCH - 1) / C::PCH;
             // what comes after this slab: next slab of this tile, or slab 0 of this workgroup's next tile
             const int ntile = last_slab ? tile + tstride : tile;
@@ -697,7 +707,7 @@ conv3d_f16_mfma(ConvArgs a)
             // ... and the K-chunks its weight stream holds (the size of its first weight piece)
             const int n_o = (bridge && !last_slab) ? (su_o + BSTEP) & (UM - 1) : 0;
             const int n_units = C::NTAP * nc8n - n_o + ((UM - ((C::NTAP * nc8n - n_o) & (UM - 1))) & ((bridge && !nlast) ? UM - 1 : 0));
-            const int n_wchunk = SPLIT == 2 ? ((n_units + 7) >> 3) << 1 : (n_units + 3) >> 2;
+            const int n_wchunk = SPLIT >= 2 ? ((n_units + 7) >> 3) << 1 : (n_units + 3) >> 2;
             const int nc0 = last_slab ? 0 : c0 + c8n;
             const size_t nwoff = last_slab ? 0 : woff + (size_t)wchunk * NF * C::FRAG;
             if constexpr (!PP && !PWM) { if (have_next) write_koff(nc8n, xb ^ 1, nslab_i); }
@@ -720,7 +730,7 @@ conv3d_f16_mfma(ConvArgs a)
                 // burst: by then every wave has read all it needs from the piece's weight buffer (so the piece after next may be fetched into
                 // it) and its share of the next piece's DMAs has landed (the MX burst reads the next piece's first fragments).
                 // Same K order, same MFMAs per accumulator as the ping-pong loop: bit-identical results.
-                static_assert(SPLIT == 2 && C::PCH == 2 && BUFH && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0 && C::XPLANE + C::xoff_of(MF - 1) < 65536,
+                static_assert(SPLIT >= 2 && C::PCH == 2 && BUFH && EPI != EPI_SIDEPOOL && C::NSEG % C::NW == 0 && C::XPLANE + C::xoff_of(MF - 1) < 65536,
                               "one-wave-per-SIMD loop: f16m8 3x3x3 kernels");
                 long long pws1 = 0;                    // SN_TIMING 4: per slab {everything in front of the piece loop since the previous slab's last piece, the piece loop}
                 constexpr int mxo = 2 * NF * 1024;
@@ -810,26 +820,32 @@ conv3d_f16_mfma(ConvArgs a)
                     // inside the MX burst, which walks the voxel fragments in its OUTER loop: 3 instead of 8 fragments' slots live at a time)
                     const unsigned ks0 = xs_a + (unsigned)(int)pw_k2, ks1 = xs_a + (unsigned)(int)(pw_k2 >> 32);
                     v4i x8h[MF][2], wa4[NF];
-                    long long wb2[NF], wsc;
-                    mx_v6i x8[MF];
-                    // two 12-byte code slots (read whole, 16 bytes each) -> one 192-bit operand: the second slot moves down by one register
+                    long long wb2[NF], wsc = 0;
+                    constexpr bool FP8 = C::MXF == 0;                    // fp8 e4m3 codes: whole 16-byte slots / 2 x 16 weight bytes per lane, no block scales
+                    v4i wa4b[FP8 ? NF : 1];                              // fp8: the second 16 bytes of a lane's weight operand (6-bit forms: wb2, 8 bytes)
+                    typedef std::conditional_t<FP8, v8i, mx_v6i> mx_op;
+                    mx_op x8[MF];
+                    // 6-bit forms: two 12-byte code slots (read whole, 16 bytes each) -> one 192-bit operand: the second slot moves down by one register;
+                    // fp8: the two slots ARE the 256-bit operand
                     auto form_x8 = [&](auto mc) {
                         constexpr int mm = decltype(mc)::value;
                         asm volatile("" : "+v"(x8h[mm][0]), "+v"(x8h[mm][1]));
-                        x8[mm] = __builtin_shufflevector(x8h[mm][0], x8h[mm][1], 0, 1, 2, 4, 5, 6);
+                        if constexpr (FP8) x8[mm] = __builtin_shufflevector(x8h[mm][0], x8h[mm][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        else x8[mm] = __builtin_shufflevector(x8h[mm][0], x8h[mm][1], 0, 1, 2, 4, 5, 6);
                         asm volatile("" : "+v"(x8[mm]));
                     };
                     constexpr int RB = 4 + 2 * NF;                        // reads 1 .. RB behind MFMAs 1 .. RB
                     static_for<0, NM>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, n = i / MF, m = i % MF;
                         pw_mfma_f16(acc[m][n], wfB[n], xfB[m]);
-                        if constexpr (i == 0) lds_read64<mxo + 1024 + 8>(wsc, wp);
+                        if constexpr (i == 0) { if constexpr (!FP8) lds_read64<mxo + 1024 + 8>(wsc, wp); }
                         else if constexpr (i <= 4) {
                             constexpr int mm = (i - 1) / 2, sl = (i - 1) & 1;
                             lds_read128i<C::XPLANE + C::xoff_of(mm)>(x8h[mm][sl], sl ? ks1 : ks0);
                         } else if constexpr (i <= RB) {
                             constexpr int j = i - 5, nn = j / 2;
-                            if constexpr (j & 1) lds_read64<mxo + nn * 2048 + 1024>(wb2[nn], wp);
+                            if constexpr ((j & 1) && FP8) lds_read128i<mxo + nn * 2048 + 1024>(wa4b[nn], wp);
+                            else if constexpr (j & 1) lds_read64<mxo + nn * 2048 + 1024>(wb2[nn], wp);
                             else lds_read128i<mxo + nn * 2048>(wa4[nn], wp);
                         } else if constexpr (i == RB + 1) lds_read32<0>(koA_n, nk_a);         // the next piece's tap offsets (ks0 / ks1 hold this piece's)
                         else if constexpr (i == RB + 2) lds_read32<16>(pw_koB, nk_a);
@@ -852,15 +868,18 @@ conv3d_f16_mfma(ConvArgs a)
                     // two operand reads of the NEXT piece's first f16 chunk, the operand of fragment m + 1 formed (its slots were requested a
                     // group ago: counted wait - LDS returns in order), and (a slab's first piece) one DMA of the next halo tile
                     typedef int v2i_ __attribute__((ext_vector_type(2)));
-                    mx_v6i wa[NF];
+                    mx_op wa[NF];
 #pragma unroll
                     for (int n = 0; n < NF; ++n) {
+                        if constexpr (FP8) wa[n] = __builtin_shufflevector(wa4[n], wa4b[n], 0, 1, 2, 3, 4, 5, 6, 7);
+                        else {
                         const v2i_ b2 = __builtin_bit_cast(v2i_, wb2[n]);
                         const v4i b4 = __builtin_shufflevector(b2, b2, 0, 1, -1, -1);
                         wa[n] = __builtin_shufflevector(wa4[n], b4, 0, 1, 2, 3, 4, 5);
+                        }
                         asm volatile("" : "+v"(wa[n]));
                     }
-                    int wsc_lo = (int)wsc, wsc_hi = (int)(wsc >> 32);
+                    int wsc_lo = FP8 ? 127 - 12 : (int)wsc, wsc_hi = (int)(wsc >> 32);      // (fp8: the lo parts of the plain weight codes carry 2^12: one E8M0 scale 2^-12 for all)
                     asm volatile("s_nop 3" : "+v"(wsc_lo), "+v"(wsc_hi));      // (VALU moves that formed the operands above -> first MFMA: the hazard is not visible to hipcc)
                     const unsigned kosA = nx_a + (unsigned)koA_n;
                     // filler slots behind MFMA n of voxel-fragment group m: n = 0, 1 the code slots of fragment m + 2; then - NF >= 7 - n = 2, 3 two next-A reads and
@@ -878,7 +897,8 @@ conv3d_f16_mfma(ConvArgs a)
                     };
                     static_for<0, NM>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, m = i / NF, n = i % NF;
-                        pw_mfma_mx6<(n & 3)>(acc[m][n], wa[n], x8[m], n < 4 ? wsc_lo : wsc_hi, mx_sb);
+                        if constexpr (FP8) pw_mfma_mx8(acc[m][n], wa[n], x8[m], wsc_lo, mx_sb);
+                        else pw_mfma_mx6<(n & 3)>(acc[m][n], wa[n], x8[m], n < 4 ? wsc_lo : wsc_hi, mx_sb);
                         if constexpr (n == 0) { if constexpr (m + 2 < MF) lds_read128i<C::XPLANE + C::xoff_of(m + 2 < MF ? m + 2 : 0)>(x8h[m + 2 < MF ? m + 2 : 0][0], ks0); }
                         else if constexpr (n == 1) { if constexpr (m + 2 < MF) lds_read128i<C::XPLANE + C::xoff_of(m + 2 < MF ? m + 2 : 0)>(x8h[m + 2 < MF ? m + 2 : 0][1], ks1); }
                         else if constexpr (n == NA_N0) next_a(IntC<2 * m>{});
@@ -912,7 +932,7 @@ conv3d_f16_mfma(ConvArgs a)
                 // a piece, the wait for the weights with the piece's last segment (the halo, younger, may stay in flight: counted wait).
                 // Measured and dropped (profiles/r3, r4 README): halo DMAs dealt out over the load slots or issued inside the burst, two chunks per
                 // segment, a scheduling barrier between operand reads and DMA duties.
-                static_assert(C::PCH >= 2 && BUFH && SPLIT != 2 && C::PTAB, "ping-pong loop (f16 / f16x3): at least two chunks per weight piece");
+                static_assert(C::PCH >= 2 && BUFH && SPLIT < 2 && C::PTAB, "ping-pong loop (f16 / f16x3): at least two chunks per weight piece");
                 const unsigned koff_a = kbuf_a + (unsigned)((xb * 8 + (last_slab ? 4 : 0) + (slab & 3)) * (C::KOFF_N * 4));
                 const unsigned xslab = xbuf_a + xb * C::XBUF;
                 constexpr int NPLM = C::NPLM;
@@ -1168,7 +1188,7 @@ conv3d_f16_mfma(ConvArgs a)
             // fetched while fragment n's MFMAs issue. Every wait counts only the reads issued AFTER the one waited for (LDS returns in order).
             // (Its round-2 refinements for the 3x3x3 f16m8 kernels - the barrier in front of a piece's last two MFMA groups, prefetch reads spread
             // over the chunk, weight fragments two groups ahead - went with those kernels' move to the ping-pong loops: profiles/r2/README.md.)
-            static_assert(KS == 1 || (K2D != 0 && SPLIT == 0), "legacy K loop: 1x1x1 layers and the 2-D one-plane f16 mode");
+            static_assert((KS == 1 && SPLIT <= 2) || (K2D != 0 && SPLIT == 0), "legacy K loop: 1x1x1 layers and the 2-D one-plane f16 mode");
             const unsigned koff_a = kbuf_a + xb * (C::KOFF_N * 4);
             unsigned xaddr[MF];
 #pragma unroll
@@ -1347,7 +1367,7 @@ conv3d_f16_mfma(ConvArgs a)
             // conv + bias + ReLU, then Pool2DLayer(2) in registers: the 2x2 pixel quad of an output lives in lanes {l, l^1} (columns)
             // x {l, l^8} (rows; l^4 for the 4x4-image fragments). max(split(y)) == split(max(y)) bit for bit because the
             // hi/lo rounding is monotone, so this equals storing the map and max-pooling the stored values. Output: [c/8][DX][D/2][D/2][8].
-            static_assert(K2D != 0, "EPI_POOL2D is a 2-D epilogue");
+            static_assert(K2D != 0 && OSPLIT <= 2 && SPLIT <= 2, "EPI_POOL2D is a 2-D epilogue (formats 0..2)");
             const int Do = D >> 1;
             const size_t VOLo = (size_t)DX * Do * Do;
             constexpr int YX = C::F4 ? 4 : 8;                       // lane distance of the row partner
@@ -1400,19 +1420,14 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (OSPLIT == 1) *reinterpret_cast<half4 *>(o + a.out_lo_off) = l;
                         if constexpr (OSPLIT == 2) {
                             char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.out_lo_off);
-                            if constexpr (SN_MX_FMT != 0) {
-                                const _Float16 hq[4] = {h[0], h[1], h[2], h[3]};
-                                sn_mx6_store_unit(slot, (ch & 7) >> 2, hq, lo32, a.mx_out_e8);
-                            } else {
-                                *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                                *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
-                            }
+                            const _Float16 hq[4] = {h[0], h[1], h[2], h[3]};
+                            sn_mx6_store_unit(slot, (ch & 7) >> 2, hq, lo32, a.mx_out_e8);
                         }
                     }
                 }
             }
         } else if constexpr (EPI == EPI_SIDEPOOL) {
-            static_assert(NF * 16 <= 96, "side conv K chunks");
+            static_assert(NF * 16 <= 96 && OSPLIT <= 2 && SPLIT <= 2, "side conv K chunks (formats 0..2)");
             const int Do = D >> 1;
             const size_t VOLo = (size_t)Do * Do * Do;
             // this layer's outputs, in registers: y[m][n][r] = ReLU(BN(acc)), fp32
@@ -1496,15 +1511,12 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (OSPLIT == 1) {
                             const uint2 lb = __builtin_bit_cast(uint2, l);
                             lw[e][0] = lb.x; lw[e][1] = lb.y;
-                        } else if constexpr (OSPLIT == 2 && SN_MX_FMT != 0) {
+                        } else if constexpr (OSPLIT == 2) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { hq[e][r] = h[r]; loq[e][r] = lo32[r]; }
-                        } else if constexpr (OSPLIT == 2) {
-                            lw[e][0] = (unsigned)sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                            lw[e][1] = (unsigned)sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
                         }
                     }
-                    if constexpr (OSPLIT == 2 && SN_MX_FMT != 0) sn_mx6_units(hq[0], loq[0], hq[1], loq[1], a.mx_side_e8, lw);
+                    if constexpr (OSPLIT == 2) sn_mx6_units(hq[0], loq[0], hq[1], loq[1], a.mx_side_e8, lw);
                     const bool st = odd ? valid[1] : valid[0];
                     const size_t my_vlin = odd ? vlin[1] : vlin[0];
                     const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
@@ -1519,12 +1531,10 @@ conv3d_f16_mfma(ConvArgs a)
                     } else if constexpr (OSPLIT == 2) {
                         const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
                         const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
-                        if constexpr (SN_MX_FMT != 0) {      // lw[e] = {low 32, high 16 bits} of the 48-bit unit of fragment e; [0]: channels 0..3, [1]: 4..7
-                            unsigned d[3];
-                            sn_mx6_join(l0[0], l1[0], l0[1], l1[1], d);
-                            if (st) *reinterpret_cast<u32x4 *>(o + a.side_lo_off) = u32x4{d[0], d[1], d[2], 0u};
-                        } else
-                        if (st) *reinterpret_cast<u32x4 *>(o + a.side_lo_off) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                        // lw[e] = {low 32, high 16 bits} of the 48-bit unit of fragment e; [0]: channels 0..3, [1]: 4..7
+                        unsigned d[3];
+                        sn_mx6_join(l0[0], l1[0], l0[1], l1[1], d);
+                        if (st) *reinterpret_cast<u32x4 *>(o + a.side_lo_off) = u32x4{d[0], d[1], d[2], 0u};
                     }
                 }
             }
@@ -1571,13 +1581,8 @@ conv3d_f16_mfma(ConvArgs a)
                         if constexpr (SPLIT == 1) *reinterpret_cast<half4 *>(o + a.pool_lo_off) = l;
                         if constexpr (SPLIT == 2) {
                             char *slot = reinterpret_cast<char *>(o - (ch & 7) + a.pool_lo_off);
-                            if constexpr (SN_MX_FMT != 0) {
-                                const _Float16 hq[4] = {h[0], h[1], h[2], h[3]};
-                                sn_mx6_store_unit(slot, (ch & 7) >> 2, hq, lo32, a.mx_out_e8);
-                            } else {
-                                *reinterpret_cast<int *>(slot + (ch & 7)) = sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                                *reinterpret_cast<int *>(slot + 8 + (ch & 7)) = sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
-                            }
+                            const _Float16 hq[4] = {h[0], h[1], h[2], h[3]};
+                            sn_mx6_store_unit(slot, (ch & 7) >> 2, hq, lo32, a.mx_out_e8);
                         }
                     }
                 }
@@ -1594,6 +1599,10 @@ conv3d_f16_mfma(ConvArgs a)
             // wave and tile in merge_conv_a, with the sigmoid's division chain laid out in the fall-through path (round 3)
             auto store_tile = [&](auto act_c) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_c)::value;
+            // storage format of the output (OSPLIT): 0 fp16 | 1 hi + lo fp16 | 2 hi + 6-bit code slots | 3 hi + fp8 code slots | 4 hi + lo + fp8 code slots
+            constexpr bool O6 = OSPLIT == 2, O8 = OSPLIT == 3 || OSPLIT == 4, OLO = OSPLIT == 1 || OSPLIT == 4;
+            static_assert(OSPLIT >= 0 && OSPLIT <= 4 && (!O6 || SN_MX_FMT != 0), "output storage format");
+            const float f8s = sn_e8_to_float(254 - a.mx_out_e8), f8lo = 4096.0f * f8s;      // fp8 slots: premultiplier 2^s (E8M0 127 - s), lo parts additionally 2^12
             const bool odd = kq & 1;
             // (opaque per-tile lane offset into the constant table: otherwise hipcc hoists the 2 * NF LDS addresses out of the tile loop, keeps
             // them live across the K loop and spills them - a scratch reload + vmcnt(0), i.e. a wait for the stores in flight, per fragment pair)
@@ -1636,7 +1645,7 @@ conv3d_f16_mfma(ConvArgs a)
                     const int nl = (blockIdx.y * NF + n) * 16 + kq * 4;
                     const bool ch_ok = nl < a.out_cp;                    // out_cp is a multiple of 8: both lanes of a pair agree
                     const f32x4 sc = scv[n], sh = shv[n];
-                    unsigned hw[2][2], lw[2][2];                          // [fragment of the pair][dword]: hi plane, second plane
+                    unsigned hw[2][2], lw[2][2], cw[2][2];                // [fragment of the pair][dword]: hi plane, lo plane, code plane
                     _Float16 hq[2][4];
                     float loq[2][4];
 #pragma unroll
@@ -1654,32 +1663,34 @@ conv3d_f16_mfma(ConvArgs a)
                         for (int r = 0; r < 4; ++r) {
                             const float pre = prev[r];
                             float y = ACT == 0 ? fmaxf(pre, 0.f) : sn_sigmoid(pre);
-                            if constexpr (OSPLIT == 1) {
+                            if constexpr (OLO) {
                                 _Float16 hh, ll;
                                 sn_split(y, hh, ll);
                                 h[r] = hh; l[r] = ll;
+                                if constexpr (O8) lo32[r] = (y - (float)hh) * f8lo;
                             } else {
                                 h[r] = (_Float16)y;
-                                lo32[r] = (y - (float)h[r]) * kMxLoMul;
+                                lo32[r] = (y - (float)h[r]) * (O8 ? f8lo : kMxLoMul);
                             }
                         }
                         const uint2 hb = __builtin_bit_cast(uint2, h);
                         hw[e][0] = hb.x; hw[e][1] = hb.y;
                         sn_track_acc(trk_acc, acc[mp + e][n]);       // (the accumulator: ReLU would turn a NaN / -inf one into a clean 0)
                         sn_track_h2(trk_h, hb.x); sn_track_h2(trk_h, hb.y);
-                        if constexpr (OSPLIT == 1) {
+                        if constexpr (OLO) {
                             const uint2 lb = __builtin_bit_cast(uint2, l);
                             lw[e][0] = lb.x; lw[e][1] = lb.y;
-                        } else if constexpr (OSPLIT == 2 && SN_MX_FMT != 0) {
+                        }
+                        if constexpr (O6) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { hq[e][r] = h[r]; loq[e][r] = lo32[r]; }
-                        } else if constexpr (OSPLIT == 2) {
-                            // second plane, 16-byte slot per (voxel, group): [fp8(hi) c0..c7 | fp8(lo*2^12) c0..c7]
-                            lw[e][0] = (unsigned)sn_pack_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-                            lw[e][1] = (unsigned)sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
+                        } else if constexpr (O8) {
+                            // code plane, 16-byte slot per (voxel, group): [fp8(hi * 2^s) c0..c7 | fp8(lo * 2^12 * 2^s) c0..c7]
+                            cw[e][0] = (unsigned)sn_pack_fp8x4((float)h[0] * f8s, (float)h[1] * f8s, (float)h[2] * f8s, (float)h[3] * f8s);
+                            cw[e][1] = (unsigned)sn_pack_fp8x4(lo32[0], lo32[1], lo32[2], lo32[3]);
                         }
                     }
-                    if constexpr (OSPLIT == 2 && SN_MX_FMT != 0) sn_mx6_units(hq[0], loq[0], hq[1], loq[1], a.mx_out_e8, lw);   // mx_format.h
+                    if constexpr (O6) sn_mx6_units(hq[0], loq[0], hq[1], loq[1], a.mx_out_e8, cw);   // mx_format.h
                     // r[0] = {own (even kq) | lower partner's fragment-(m+1) half (odd kq)}, r[1] = {upper partner's fragment-m half | own}
                     const auto h0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
                     const auto h1 = __builtin_amdgcn_permlane16_swap(hw[0][1], hw[1][1], false, false);
@@ -1688,19 +1699,21 @@ conv3d_f16_mfma(ConvArgs a)
                     _Float16 *o = reinterpret_cast<_Float16 *>(plane + my_voff);
                     const bool st = my_valid && ch_ok;
                     if (st) *reinterpret_cast<u32x4 *>(o) = u32x4{h0[0], h1[0], h0[1], h1[1]};
-                    if constexpr (OSPLIT == 1) {
+                    if constexpr (OLO) {
                         const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);
                         const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);
                         if (st) *reinterpret_cast<u32x4 *>(o + a.out_lo_off) = u32x4{l0[0], l1[0], l0[1], l1[1]};
-                    } else if constexpr (OSPLIT == 2) {
-                        const auto l0 = __builtin_amdgcn_permlane16_swap(lw[0][0], lw[1][0], false, false);   // fp8(hi) words
-                        const auto l1 = __builtin_amdgcn_permlane16_swap(lw[0][1], lw[1][1], false, false);   // fp8(lo) words
-                        if constexpr (SN_MX_FMT != 0) {
+                    }
+                    if constexpr (O6 || O8) {
+                        const auto c0 = __builtin_amdgcn_permlane16_swap(cw[0][0], cw[1][0], false, false);   // 6-bit: low 32 bits of the units; fp8: the hi-code words
+                        const auto c1 = __builtin_amdgcn_permlane16_swap(cw[0][1], cw[1][1], false, false);   // 6-bit: high 16 bits;               fp8: the lo-code words
+                        _Float16 *const oc = o + (OSPLIT == 4 ? a.out_code_off : a.out_lo_off);
+                        if constexpr (O6) {
                             unsigned d[3];
-                            sn_mx6_join(l0[0], l1[0], l0[1], l1[1], d);
-                            if (st) *reinterpret_cast<u32x4 *>(o + a.out_lo_off) = u32x4{d[0], d[1], d[2], 0u};
+                            sn_mx6_join(c0[0], c1[0], c0[1], c1[1], d);
+                            if (st) *reinterpret_cast<u32x4 *>(oc) = u32x4{d[0], d[1], d[2], 0u};
                         } else
-                        if (st) *reinterpret_cast<u32x4 *>(o + a.out_lo_off) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                        if (st) *reinterpret_cast<u32x4 *>(oc) = u32x4{c0[0], c0[1], c1[0], c1[1]};
                     }
                 }
             }

@@ -30,26 +30,12 @@ __device__ __forceinline__ void sn_load8(const _Float16 *p, long long lo_off, fl
         for (int e = 0; e < 8; ++e) v[e] = (float)q[e] + (float)ql[e];
     } else {
         const uint4 s = *reinterpret_cast<const uint4 *>(p + lo_off);
-#if SN_MX_FMT == 0
-        const float sc = 1.0f / kMxLoMul;
-        v[0] = (float)q[0] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 0) * sc; v[1] = (float)q[1] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 1) * sc;
-        v[2] = (float)q[2] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 2) * sc; v[3] = (float)q[3] + __builtin_amdgcn_cvt_f32_fp8((int)s.z, 3) * sc;
-        v[4] = (float)q[4] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 0) * sc; v[5] = (float)q[5] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 1) * sc;
-        v[6] = (float)q[6] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 2) * sc; v[7] = (float)q[7] + __builtin_amdgcn_cvt_f32_fp8((int)s.w, 3) * sc;
-#else
         // codes [hi c0..3 | lo c0..3 | hi c4..7 | lo c4..7] of (value * 2^(127 - e8)); lo additionally * 2^kMxLoExp
         const mx_v32f d = sn_mx6_decode(mx_v6i{(int)s.x, (int)s.y, (int)s.z, 0, 0, 0});
         const float sc = sn_e8_to_float(e8) / kMxLoMul;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = (float)q[e] + d[4 + e] * sc; v[4 + e] = (float)q[4 + e] + d[12 + e] * sc; }
-#endif
     }
-}
-__device__ __forceinline__ int sn_fp8x4(float a, float b, float c, float d)
-{
-    auto cl = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
-    int r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
-    return __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
 }
 template <int SPLIT>
 __device__ __forceinline__ void sn_store8(_Float16 *p, long long lo_off, const float (&v)[8], int e8 = kMxActE8)
@@ -69,12 +55,6 @@ __device__ __forceinline__ void sn_store8(_Float16 *p, long long lo_off, const f
         *reinterpret_cast<h8 *>(p + lo_off) = l;
     } else if constexpr (SPLIT == 2) {
         uint4 s;
-#if SN_MX_FMT == 0
-        s.x = (unsigned)sn_fp8x4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-        s.y = (unsigned)sn_fp8x4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
-        s.z = (unsigned)sn_fp8x4(lo[0] * kMxLoMul, lo[1] * kMxLoMul, lo[2] * kMxLoMul, lo[3] * kMxLoMul);
-        s.w = (unsigned)sn_fp8x4(lo[4] * kMxLoMul, lo[5] * kMxLoMul, lo[6] * kMxLoMul, lo[7] * kMxLoMul);
-#else
         mx_v32h t = {};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -83,7 +63,6 @@ __device__ __forceinline__ void sn_store8(_Float16 *p, long long lo_off, const f
         }
         const mx_v6i c = sn_mx6_cvt(t, e8);
         s.x = (unsigned)c[0]; s.y = (unsigned)c[1]; s.z = (unsigned)c[2]; s.w = 0u;
-#endif
         *reinterpret_cast<uint4 *>(p + lo_off) = s;
     }
 }

@@ -18,8 +18,8 @@
 #ifndef SN_MX_FMT
 #define SN_MX_FMT 2
 #endif
-static_assert(SN_MX_FMT == 0 || SN_MX_FMT == 2 || SN_MX_FMT == 3, "SN_MX_FMT: 0 fp8 e4m3, 2 fp6 e2m3, 3 bf6 e3m2");
-constexpr int kMxLoExp = SN_MX_FMT ? 11 : 12;
+static_assert(SN_MX_FMT == 2 || SN_MX_FMT == 3, "SN_MX_FMT: 2 fp6 e2m3, 3 bf6 e3m2 (fp8 e4m3 is a per-kernel format since round 5: conv3d_mfma.h SPLIT 3)");
+constexpr int kMxLoExp = 11;
 constexpr float kMxLoMul = (float)(1 << kMxLoExp);
 // Static premultipliers 2^s of the code planes (fp6 forms), as E8M0 exponents 127 - s. Sized for what the tensors hold after the exact
 // power-of-two renormalisation of sn_load_weights: ReLU(BN(.)) outputs of O(1) ("act"), and the concat buffer of sigmoid side outputs in
@@ -32,12 +32,13 @@ constexpr float kMxLoMul = (float)(1 << kMxLoExp);
 #define SN_MX_S_CAT 2
 #endif
 #ifndef SN_MX_S_C4
-#define SN_MX_S_C4 (-2)     // conv4_1's and conv4_2's outputs (default mode, round 5: conv4_2 / conv4_3 on the MX step): ReLU outputs whose tail real pixels stretch far beyond what
-#endif                      // noise inputs show - modelled L_inf on real DTU / dino pixels 4.2e-4 under s = -1, 1.3e-4 under s = -2 (range 30), 1.4e-4 .. 1.7e-4 under s = -3 (tools/format_table.py)
-constexpr int kMxActE8 = SN_MX_FMT ? 127 - SN_MX_S_ACT : 127;
-constexpr int kMxC4E8 = SN_MX_FMT ? 127 - (SN_MX_S_C4) : 127;
-constexpr int kMxCatE8 = SN_MX_FMT ? 127 - SN_MX_S_CAT : 127;
-constexpr int kMxX0E8 = SN_MX_FMT ? 127 + 5 : 127;      // the network input (f16m8 mode only): mean-subtracted 8-bit colours, |x| < 256 -> 2^-5
+#define SN_MX_S_C4 0        // the FP8 e4m3 code planes of the conv4 chain (conv3d_mfma.h SPLIT 3; conv3_3's, conv4_1's, conv4_2's outputs): codes of the values themselves -
+#endif                      // normal range 2^-6 .. 448. Measured on the device, s = -2 .. +1 are equivalent (worst L_inf 1.56e-4 .. 1.74e-4), s = 3: 2.3e-4, s = 4: 8.6e-4 -
+                            // scene cubes hold activations beyond 28, which is what the 6-bit codes of the merge layers could not represent here (profiles/r5/README.md)
+constexpr int kMxActE8 = 127 - SN_MX_S_ACT;
+constexpr int kMxC4E8 = 127 - (SN_MX_S_C4);
+constexpr int kMxCatE8 = 127 - SN_MX_S_CAT;
+constexpr int kMxX0E8 = 127 + 5;      // the network input (f16m8 mode only): mean-subtracted 8-bit colours, |x| < 256 -> 2^-5
 
 typedef int mx_v6i __attribute__((ext_vector_type(6)));
 typedef _Float16 mx_v32h __attribute__((ext_vector_type(32)));

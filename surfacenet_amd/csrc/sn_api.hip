@@ -125,20 +125,20 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
     // same number of channel groups and whose units per slab are not a multiple of 4: the last K-chunk of a slab is filled up with the first
     // b units of the next slab, which starts at its unit o = b
     {
-        const int um = split == 2 ? 8 : 4;                  // units per K-chunk (f16x3) / per weight piece (f16m8)
-        bool ok = L.bridge && (split == 1 || (split == 2 && !L.k2d && SN_MX_FMT != 0)) && L.ks == 3 && L.slab_c8.size() >= 2 && (ntap * cs8max) % um != 0;
+        const int um = split >= 2 ? 8 : 4;                  // units per K-chunk (f16x3) / per weight piece (f16m8)
+        bool ok = L.bridge && (split == 1 || (split >= 2 && !L.k2d)) && L.ks == 3 && L.slab_c8.size() >= 2 && (ntap * cs8max) % um != 0;
         for (unsigned char c8n : L.slab_c8) ok = ok && c8n == cs8max;
         L.bridge = ok ? 1 : 0;
     }
     const int nslab = (int)L.slab_c8.size();
     // units of slab si in its chunks / pieces: GU - o of its own + b of the next slab's (the kernel's slab_units)
     auto slab_units = [&](int si, int c8n, int &o, int &b) {
-        const int GU = ntap * c8n, um = split == 2 ? 8 : 4;
+        const int GU = ntap * c8n, um = split >= 2 ? 8 : 4;
         o = 0; b = 0;
         if (L.bridge) { o = (si * ((um - GU % um) % um)) % um; b = (si + 1 == nslab) ? 0 : (um - (GU - o) % um) % um; }
         return GU - o + b;
     };
-    if (split != 2) {
+    if (split < 2) {
         long long chunks = 0;
         for (int si = 0; si < nslab; ++si) { int o, b; chunks += (slab_units(si, L.slab_c8[si], o, b) + 3) / 4; }
         L.wsplit_stride = chunks * nf * 512 * npl;
@@ -203,7 +203,7 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
                         for (int lane = 0; lane < 64; ++lane) {
                             const int o = (ns * nf + f) * 16 + (lane & 15), q = lane >> 4;
                             unsigned char *frag = mx + (size_t)f * 2048;   // two lane-linear 1 KiB halves: k bytes 0-15 | 16-31
-                            if (SN_MX_FMT != 0) {
+                            if (split == 2) {
                                 // 6-bit forms: lane quarter q covers groups 8p+2q (elements 0..15 of its 32-element block) and 8p+2q+1 (16..31), one
                                 // E8M0 scale per block. Code position within a group follows the
                                 // activation slot [x_hi c0..3 | x_lo c0..3 | x_hi c4..7 | x_lo c4..7] with the OTHER part of the weight: w_lo * 2^L
@@ -246,6 +246,7 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
                                 (mx + 1024 + lane * 16 + 8)[f] = (unsigned char)std::max(0, std::min(254, 127 + E - kMxLoExp));
                                 continue;
                             }
+                            constexpr float kLo8 = 4096.0f;     // fp8 e4m3 form (split 3): lo parts premultiplied by 2^12, undone by the MX step's A-side scale (E8M0 115)
                             for (int i = 0; i < 4; ++i) {
                                 // fp8 form: lane quarter q covers groups 8p+2q, 8p+2q+1, 8-byte sections [w_lo | w_hi | w_lo | w_hi] (the activation slots read [x_hi | x_lo])
                                 const int g = 8 * p + 2 * q + (i >> 1);
@@ -255,7 +256,7 @@ static int pack_conv_host(PackedConv &L, const float *W_in, const float *beta, c
                                     const float w = wslot(o, g, j);
                                     const float hi = (float)(_Float16)w;
                                     const int kb = i * 8 + j;
-                                    frag[(kb >> 4) * 1024 + lane * 16 + (kb & 15)] = lo_part ? fp8_e4m3((w - hi) * kMxLoMul) : fp8_e4m3(hi);
+                                    frag[(kb >> 4) * 1024 + lane * 16 + (kb & 15)] = lo_part ? fp8_e4m3((w - hi) * kLo8) : fp8_e4m3(hi);
                                 }
                             }
                         }
@@ -418,22 +419,34 @@ static int run_net_t(sn_ctx *c, int S, float *unf)
     }
     RUN((launch_conv<CONV3>(c, L["conv3_1"], p2, 80, a3, 160, 0, 160, nullptr, S, D3)));
     RUN((launch_conv<CONV3>(c, L["conv3_2"], a3, 160, b3, 160, 0, 160, nullptr, S, D3)));
-    RUN((launch_conv<CONV3>(c, L["conv3_3"], b3, 160, a3, 160, 0, 160, nullptr, S, D3)));
-    RUN((launch_conv<SIDE>(c, L["side_op3"], a3, 160, s3, 16, 0, 16, nullptr, S, D3)));
+    // Round 5, default mode: the dilated chain conv4_1 .. conv4_3 in the f16m8e arithmetic - the main term on the f16 MFMA, both correction terms on ONE fp8 e4m3
+    // MX MFMA per 64 k (2 MFMA units per product instead of 3) - on the one-wave-per-SIMD loop. fp8, not the merge layers' 6-bit codes: those ran 20 % faster
+    // still but their static range cannot hold the conv4 chain's data-dependent outliers (3.6e-4 .. 4.3e-4 on scene cubes; profiles/r5/README.md). conv3_3's
+    // output has readers of both kinds - side_op3 reads hi + lo planes, conv4_1 hi + code slots - and is stored with three planes; conv4_1 / conv4_2 store
+    // hi + codes; conv4_3 stores hi + lo again (side_op4).
     bool c4_done = false;
-    if constexpr (SP == 1 && SN_MX_FMT != 0) {
-        if (c->c4_m6) {
-            // Round 5: conv4_2 and conv4_3 in the f16m8 arithmetic (the main term on the f16 MFMA, both correction terms on ONE 6-bit MX MFMA per 64 k: 1.5 MFMA
-            // units per product instead of 3) on the one-wave-per-SIMD loop, their input code planes under the premultiplier 2^-2 (mx_c4_e8; chosen on the model of
-            // the arithmetic, tools/format_table.py: the static range must hold real pixels' outliers). conv4_1 stays on three fp16 MFMAs - with it the modelled
-            // L_inf leaves the 1.5e-4 budget - and stores hi + codes for conv4_2; conv4_3 stores hi + lo again (side_op4 reads it in three-fp16-MFMA arithmetic).
-            RUN((launch_conv<3, 2, 4, 5, EPI_STORE, 1, 1, 2, 8, 0, 0, 2>(c, L["conv4_1"], a3, 160, a4, 304, 0, 304, nullptr, S, D3)));
-            RUN((launch_conv<3, 2, 8, 5, EPI_STORE, 2, 1, 2, 4, 0>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
-            RUN((launch_conv<3, 2, 8, 5, EPI_STORE, 2, 1, 2, 4, 0, 0, 1>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
+    if constexpr (SP == 1) {
+        if (c->c4_m8 == 2) {      // (A/B: conv4_1 stays on three fp16 MFMAs and stores hi + codes for conv4_2)
+            RUN((launch_conv<CONV3>(c, L["conv3_3"], b3, 160, a3, 160, 0, 160, nullptr, S, D3)));
+            RUN((launch_conv<SIDE>(c, L["side_op3"], a3, 160, s3, 16, 0, 16, nullptr, S, D3)));
+            RUN((launch_conv<3, 2, 4, 5, EPI_STORE, 1, 1, 2, 8, 0, 0, 3>(c, L["conv4_1"], a3, 160, a4, 304, 0, 304, nullptr, S, D3)));
+            RUN((launch_conv<3, 2, 8, 5, EPI_STORE, 3, 1, 2, 4, 0>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
+            RUN((launch_conv<3, 2, 8, 5, EPI_STORE, 3, 1, 2, 4, 0, 0, 1>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
+            c4_done = true;
+        } else
+        if (c->c4_m8) {
+            const Act a3o{a3.p, a3.lo, (long long)(c->a3c - a3.p)}, a3i{a3.p, (long long)(c->a3c - a3.p)};
+            RUN((launch_conv<3, 1, 4, 5, EPI_STORE, 1, C23_CS8, C23_PCH, 8, 0, 0, 4>(c, L["conv3_3"], b3, 160, a3o, 160, 0, 160, nullptr, S, D3)));
+            RUN((launch_conv<SIDE>(c, L["side_op3"], a3, 160, s3, 16, 0, 16, nullptr, S, D3)));
+            RUN((launch_conv<3, 2, 8, 5, EPI_STORE, 3, 1, 2, 4, 0>(c, L["conv4_1"], a3i, 160, a4, 304, 0, 304, nullptr, S, D3)));
+            RUN((launch_conv<3, 2, 8, 5, EPI_STORE, 3, 1, 2, 4, 0>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
+            RUN((launch_conv<3, 2, 8, 5, EPI_STORE, 3, 1, 2, 4, 0, 0, 1>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
             c4_done = true;
         }
     }
     if (!c4_done) {
+    RUN((launch_conv<CONV3>(c, L["conv3_3"], b3, 160, a3, 160, 0, 160, nullptr, S, D3)));
+    RUN((launch_conv<SIDE>(c, L["side_op3"], a3, 160, s3, 16, 0, 16, nullptr, S, D3)));
     RUN((launch_conv<CONV4>(c, L["conv4_1"], a3, 160, a4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<CONV4>(c, L["conv4_2"], a4, 304, b4, 304, 0, 304, nullptr, S, D3)));
     RUN((launch_conv<CONV4>(c, L["conv4_3"], b4, 304, a4, 304, 0, 304, nullptr, S, D3)));
@@ -548,6 +561,10 @@ static int ensure_workspace(sn_ctx *c)
     AL(s3, S * v3 * 16); AL(s4, S * v3 * 16);
     AL(ma, S * v1 * 104);
 #undef AL
+    if (c->split == 1) {      // default mode: the fp8 code plane of conv3_3's output (read by conv4_1; side_op3 reads the hi / lo planes)
+        if ((rc = dev_alloc(c, &c->a3c, (size_t)(S * v3 * 160))) != SN_OK) return rc;
+        c->ws_owned.push_back(c->a3c);
+    }
 
     c->ws_ready = true; c->ws_split = c->split;
     return SN_OK;
@@ -595,7 +612,7 @@ static void reset_mx_exponents(sn_ctx *c)
 {
     c->mx_act_e8 = kMxActE8; c->mx_cat_e8 = kMxCatE8; c->mx_c4_e8 = kMxC4E8;
     if (c->mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0) {                                    // accuracy sweeps only (mx_format.h)
-        if (sn_ab_switch("SN_MX_S_C4")) c->mx_c4_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_C4"))));
+        if (sn_ab_switch("SN_MX_S_C4")) c->mx_c4_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_C4"))));      // (the fp8 code planes of the conv4 chain)
         if (sn_ab_switch("SN_MX_S_ACT")) c->mx_act_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_ACT"))));
         if (sn_ab_switch("SN_MX_S_CAT")) c->mx_cat_e8 = 127 - std::max(-8, std::min(8, atoi(sn_ab_switch("SN_MX_S_CAT"))));
     }
@@ -611,13 +628,10 @@ int sn_set_precision(sn_ctx *c, int mode)
     c->split = mode == SN_PRECISION_F16X3_PURE ? 1 : mode;
     c->tail_m8 = mode == SN_PRECISION_F16X3 ? 2 : 0;
     c->last_run_samples = 0;
-    // conv4_2 / conv4_3 on the 6-bit MX step (run_net_t): MEASURED AND NOT TAKEN - 7,290 -> 7,600 cubes/s (conv4_x 1.48 -> 1.10 ms), the real-pixel windows at
-    // L_inf 1.2e-4 .. 1.3e-4 as modelled, but cubes of the dataset scenes (noise views, partly out of view: tests/test_gpu_configs.py) at 3.6e-4 .. 4.3e-4: a
-    // STATIC premultiplier cannot hold data-dependent outliers (profiles/r5/README.md). Test-only twin: SN_C4_M6=1.
-    c->c4_m6 = false;
-    if (mode == SN_PRECISION_F16X3 && SN_MX_FMT != 0 && sn_ab_switch("SN_C4_M6")) c->c4_m6 = atoi(sn_ab_switch("SN_C4_M6")) != 0;
+    c->c4_m8 = mode == SN_PRECISION_F16X3 ? 1 : 0;                                                  // conv4_1 .. conv4_3 on the fp8 MX step (run_net_t)
+    if (c->c4_m8 && sn_ab_switch("SN_C4_M8")) c->c4_m8 = std::max(0, std::min(2, atoi(sn_ab_switch("SN_C4_M8"))));       // A/B measurements only (test-only twin)
     if (mode == SN_PRECISION_F16X3 && sn_ab_switch("SN_M8_TAIL")) c->tail_m8 = atoi(sn_ab_switch("SN_M8_TAIL")) >= 2 ? 2 : 0;   // A/B measurements only (0 = f16x3p's arithmetic)
-    if (c->tail_m8 < 2) c->c4_m6 = false;
+    if (c->tail_m8 < 2) c->c4_m8 = 0;
     reset_mx_exponents(c);
     return SN_OK;
 }
@@ -700,32 +714,26 @@ int sn_calibrate_dev(sn_ctx *c, int n_samples, double max_sat_fraction, sn_calib
     HIPCHK(hipSetDevice(c->device));
     const long long vox = (long long)c->s * c->s * c->s;
     const float lim = SN_MX_FMT == 2 ? 7.5f : 28.f;
-    // three code planes: 0 "act" = merge_conv_a's output, 1 "cat" = the concat buffer, 2 "c4" = conv4_1's and conv4_2's outputs (what a forward call leaves
-    // of them: conv4_2's output and, where conv4_1's was, conv4_3's - the same kind of tensor)
-    constexpr int NT = 3, HB = kMxScanBins + 2;
+    // two 6-bit code planes: 0 "act" = merge_conv_a's output, 1 "cat" = the concat buffer (the conv4 chain's fp8 codes have the exponent range: nothing to calibrate)
+    constexpr int NT = 2, HB = kMxScanBins + 2;
     TmpDev tmp;
     unsigned long long *d_hist = tmp.get<unsigned long long>(NT * HB);
     if (!d_hist) return fail(SN_ERR_HIP, "out of device memory");
     HIPCHK(hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * NT * HB, c->stream));
-    struct Scan { const _Float16 *t; long long halfs; int slot; };
-    std::vector<Scan> scans = {{c->ma, (long long)n_samples * vox * 104, 0}, {c->cat, (long long)n_samples * vox * 64, 1}};
-    if (c->c4_m6) {
-        const long long v3 = vox / 64;
-        scans.push_back({c->b4, (long long)n_samples * v3 * 304, 2});
-        scans.push_back({c->a4, (long long)n_samples * v3 * 304, 2});
-    }
-    for (const Scan &sc : scans)
-        hipLaunchKernelGGL(mx_scan_kernel, dim3((unsigned)std::min<long long>(2048, (sc.halfs / 8 + 255) / 256)), dim3(256), 0, c->stream, sc.t, sc.halfs, lim,
-                           d_hist + sc.slot * HB);
+    const _Float16 *tens[NT] = {c->ma, c->cat};
+    const long long halfs[NT] = {(long long)n_samples * vox * 104, (long long)n_samples * vox * 64};
+    for (int t = 0; t < NT; ++t)
+        hipLaunchKernelGGL(mx_scan_kernel, dim3((unsigned)std::min<long long>(2048, (halfs[t] / 8 + 255) / 256)), dim3(256), 0, c->stream, tens[t], halfs[t], lim,
+                           d_hist + t * HB);
     HIPCHK(hipGetLastError());
     unsigned long long h[NT][HB];
     HIPCHK(hipMemcpyAsync(h, d_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int s_new[NT];
     double sat_new[NT], sat_old[NT];
-    const int s_old[NT] = {127 - c->mx_act_e8, 127 - c->mx_cat_e8, 127 - c->mx_c4_e8};
+    const int s_old[NT] = {127 - c->mx_act_e8, 127 - c->mx_cat_e8};
     for (int t = 0; t < NT; ++t) {
-        if (h[t][kMxScanBins] == 0) {      // an all-zero (or unscanned) tensor says nothing about its range: the exponent stays
+        if (h[t][kMxScanBins] == 0) {      // an all-zero tensor says nothing about its range: the exponent stays
             s_new[t] = s_old[t]; sat_new[t] = sat_old[t] = 0.0;
             continue;
         }
@@ -734,9 +742,6 @@ int sn_calibrate_dev(sn_ctx *c, int n_samples, double max_sat_fraction, sn_calib
         int s = -kMxScanBins / 2;
         for (int cand = kMxScanBins / 2; cand >= -kMxScanBins / 2; --cand)
             if (frac(cand) <= max_sat_fraction) { s = cand; break; }
-        // (c4: three chained 300-channel layers accumulate what saturated codes lose - under the 1e-3 bound s = 0 may pass where the model of the arithmetic
-        // puts the optimum at the static s = -1 (tools/format_table.py) - so the calibration only ever WIDENS that plane's range beyond the static choice)
-        if (t == 2) s = std::min(s, SN_MX_S_C4);
         if (measure_only) s = s_old[t];
         s_new[t] = s; sat_new[t] = frac(s); sat_old[t] = frac(std::max(-kMxScanBins / 2, std::min(kMxScanBins / 2, s_old[t])));
     }
@@ -744,8 +749,7 @@ int sn_calibrate_dev(sn_ctx *c, int n_samples, double max_sat_fraction, sn_calib
     out->s_act_before = s_old[0]; out->s_cat_before = s_old[1]; out->s_act = s_new[0]; out->s_cat = s_new[1];
     out->sat_act_before = sat_old[0]; out->sat_cat_before = sat_old[1]; out->sat_act = sat_new[0]; out->sat_cat = sat_new[1];
     out->max_act = f16_of(h[0][kMxScanBins + 1]); out->max_cat = f16_of(h[1][kMxScanBins + 1]);
-    out->s_c4_before = s_old[2]; out->s_c4 = s_new[2]; out->sat_c4_before = sat_old[2]; out->sat_c4 = sat_new[2]; out->max_c4 = f16_of(h[2][kMxScanBins + 1]);
-    c->mx_act_e8 = 127 - s_new[0]; c->mx_cat_e8 = 127 - s_new[1]; c->mx_c4_e8 = 127 - s_new[2];
+    c->mx_act_e8 = 127 - s_new[0]; c->mx_cat_e8 = 127 - s_new[1];
     return SN_OK;
 }
 
@@ -836,8 +840,8 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
         }
         PackedConv L;
         L.name = sp.name; L.cin = sp.cin; L.cout = sp.cout; L.ks = k; L.dil = (sp.kind == K_DIL3) ? 2 : 1; L.act = sp.act;
-        const int lsplit = (c->split == 1 && ((c->tail_m8 >= 2 && (L.name == "merge_conv_b" || L.name == "merge_conv_a")) ||
-                                              (c->c4_m6 && (L.name == "conv4_2" || L.name == "conv4_3")))) ? 2 : c->split;   // see run_net_t
+        const int lsplit = (c->split == 1 && c->tail_m8 >= 2 && (L.name == "merge_conv_b" || L.name == "merge_conv_a")) ? 2 :
+                           ((c->split == 1 && c->c4_m8 && sp.kind == K_DIL3 && !(c->c4_m8 == 2 && L.name == "conv4_1")) ? 3 : c->split);   // see run_net_t
         const TileChoice tc = tile_for(sp, lsplit);
         std::vector<int> &oe = out_exps[sp.name];
         oe.assign(sp.cout, 0);
@@ -847,7 +851,7 @@ int sn_load_weights(sn_ctx *c, const float *blob, size_t n_floats, const sn_para
                 if (m > 0.f && std::isfinite(m)) oe[o] = std::max(-60, std::min(60, -std::ilogb(m)));
             }
         static const bool no_bridge = sn_ab_switch("SN_NO_BRIDGE") != nullptr;               // (A/B switch)
-        L.bridge = ((lsplit == 1 || lsplit == 2) && k == 3 && !no_bridge) ? 1 : 0;   // 27 K-chunks per four slabs instead of 28 (f16x3), 27 weight pieces per eight slabs instead of 32 (f16m8): pack_conv_host decides
+        L.bridge = (lsplit >= 1 && k == 3 && !no_bridge) ? 1 : 0;   // 27 K-chunks per four slabs instead of 28 (f16x3), 27 weight pieces per eight slabs instead of 32 (f16m8): pack_conv_host decides
         if ((rc = pack_conv(c, L, W, beta, gamma, mean, inv_std, tc.nf, tc.nsplit, tc.cs8max, lsplit, in_exp, oe.data())) != SN_OK) return rc;
         c->conv[L.name] = L;
     }

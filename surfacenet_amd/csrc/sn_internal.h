@@ -101,8 +101,9 @@ struct sn_ctx {
     bool have_weights = false, have_relw = false;
     int split = 1;              // 0: f16 operands; 1: f16x3 (hi/lo split operands, fp32-class results) — default; 2: f16m8
     int mode = 1;               // the SN_PRECISION_* value given to sn_set_precision
-    int mx_c4_e8 = kMxC4E8;     // ... of conv4_1's and conv4_2's outputs when conv4_2 / conv4_3 run in the f16m8 arithmetic (c4_m6)
-    bool c4_m6 = false;         // experiment (off): conv4_2 / conv4_3 with their correction terms on the 6-bit MX MFMA (sn_set_precision)
+    int mx_c4_e8 = kMxC4E8;     // ... of the fp8 code planes of the conv4 chain (conv3_3's, conv4_1's, conv4_2's outputs) when it runs in the f16m8e arithmetic (c4_m8)
+    int c4_m8 = 1;              // default mode, round 5: conv4_1 .. conv4_3 with their correction terms on the fp8 e4m3 MX MFMA (2 MFMA units per product instead of 3)
+    _Float16 *a3c = nullptr;    // code plane of conv3_3's output, [max_samples][160/8][D/4]^3 slots of 16 bytes
     int mx_act_e8 = kMxActE8, mx_cat_e8 = kMxCatE8;   // mx_format.h; SN_MX_S_ACT / SN_MX_S_CAT in the environment override them in the default (hybrid) mode
     int tail_m8 = 2;            // f16x3: 2 = merge_conv_a + merge_conv_b run their two correction terms on the MX MFMA (the default), 0 = none (f16x3p)
     bool ws_ready = false; int ws_split = -1;
@@ -235,7 +236,7 @@ static bool shape_is(const sn_param_desc &d, std::initializer_list<int> s)
 // launches
 // ------------------------------------------------------------------------------------------------
 // A channels-last fp16 activation tensor: hi plane at p, lo plane (f16x3 mode) at p + lo elements.
-struct Act { _Float16 *p; long long lo; };
+struct Act { _Float16 *p; long long lo; long long code = 0; };      // code: a third plane of fp8 code slots (OSPLIT 4), in halfs from p
 
 // What EPI_SIDEPOOL needs beside the conv's own arguments: the fused 1x1x1 layer and the two destinations.
 struct SideFuse { const PackedConv *side; Act side_out; int side_cs, side_coff; Act pool_out; int pool_cs; };
@@ -251,7 +252,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
         return fail(SN_ERR_STATE, "%s: packed for a different kernel configuration", L.name.c_str());
     ConvArgs a;
     memset(&a, 0, sizeof a);
-    a.in = in.p; a.in_lo_off = in.lo; a.out = out.p; a.out_lo_off = out.lo; a.out_f32 = out_f32;
+    a.in = in.p; a.in_lo_off = in.lo; a.out = out.p; a.out_lo_off = out.lo; a.out_code_off = out.code; a.out_f32 = out_f32;
     a.wpack = L.wpack; a.scale = L.scale; a.shift = L.shift;
     a.w3 = c->w3; a.scale3 = c->scale3; a.shift3 = c->shift3; a.zero_page = c->zero_page;
     a.wsplit_stride = L.wsplit_stride;
@@ -276,7 +277,7 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
     {
         // static premultipliers of the 6-bit code planes (mx_format.h): the concat buffer holds sigmoid outputs, everything else ReLU(BN(.))
         auto e8_of = [&](const _Float16 *t) {
-            if (t && c->c4_m6 && c->split == 1 && (t == c->a4 || t == c->b4)) return c->mx_c4_e8;
+            if (t && c->c4_m8 && c->split == 1 && (t == c->a3 || t == c->a4 || t == c->b4)) return c->mx_c4_e8;
             return t && t == c->cat ? c->mx_cat_e8 : (t && t == c->x0 ? kMxX0E8 : c->mx_act_e8);
         };
         a.mx_in_e8 = e8_of(in.p); a.mx_out_e8 = e8_of(out.p); a.mx_side_e8 = sf ? e8_of(sf->side_out.p) : c->mx_act_e8;
@@ -295,8 +296,9 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
         if (it == c->num_names.end() && c->num_names.size() < 31) c->num_names.push_back(L.name);
         a.status = c->d_num;
         // saturation warning: only for tensors stored with a 6-bit code plane whose values are not bounded by construction (ReLU outputs)
-        if (EPI == EPI_STORE && (OSPLIT < 0 ? SPLIT : OSPLIT) == 2 && SN_MX_FMT != 0 && L.act == 0) {
-            const _Float16 lim = (_Float16)std::ldexp(SN_MX_FMT == 2 ? 7.5f : 28.f, a.mx_out_e8 - 127);
+        constexpr int OS = OSPLIT < 0 ? SPLIT : OSPLIT;
+        if (EPI == EPI_STORE && OS >= 2 && L.act == 0) {
+            const _Float16 lim = (_Float16)std::min(60000.f, std::ldexp(OS >= 3 ? 448.f : (SN_MX_FMT == 2 ? 7.5f : 28.f), a.mx_out_e8 - 127));
             unsigned short bits; memcpy(&bits, &lim, 2);
             a.mx_sat_bits = bits;
         }

@@ -161,6 +161,6 @@ def test_ab_switches_exist_in_the_test_twin_only():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prod = open(os.path.join(root, "surfacenet_amd", "libsurfacenet_hip.so"), "rb").read()
     dbg = open(os.path.join(root, "surfacenet_amd", "libsurfacenet_hip_dbg.so"), "rb").read()
-    for name in (b"SN_NO_BRIDGE", b"SN_SIMIL_NO_BRIDGE", b"SN_NO_EPI_FUSION", b"SN_UPSAMPLE_PER_VOXEL", b"SN_M8_TAIL", b"SN_MX_S_ACT", b"SN_MX_S_CAT", b"SN_C4_M6"):
+    for name in (b"SN_NO_BRIDGE", b"SN_SIMIL_NO_BRIDGE", b"SN_NO_EPI_FUSION", b"SN_UPSAMPLE_PER_VOXEL", b"SN_M8_TAIL", b"SN_MX_S_ACT", b"SN_MX_S_CAT", b"SN_C4_M8"):
         assert name in dbg, name
         assert name not in prod, name

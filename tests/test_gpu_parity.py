@@ -416,7 +416,9 @@ def test_epilogue_fusion_equals_separate_launches(gpu_required, tmp_path):
     for k in outs[0].files:
         a, b = outs[0][k], outs[1][k]
         # f16x3: fp32-class; f16m8: the stand-alone side kernel computes in f16m8, the fused one on three fp16 MFMAs; f16: fp16-class
-        tol = 2e-3 if "_f16_" in k else (1e-3 if "_f16m8_" in k else 2e-5)
+        # (f16x3: the side maps differ in their last fp32 bits; what the merge layers' 6-bit codes make of that - a flipped code is 2^-15 of its value - reaches
+        # 2e-5 .. 3e-5 of a probability, depending on the operating point: observed 1.8e-5 in round 4, 3.1e-5 since the conv4 chain's arithmetic changed)
+        tol = 2e-3 if "_f16_" in k else (1e-3 if "_f16m8_" in k else 5e-5)
         assert a.shape == b.shape and np.abs(a - b).max() < tol, (k, float(np.abs(a - b).max()))
 
 

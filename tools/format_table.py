@@ -33,10 +33,11 @@ def tab(**kw):
 
 
 CANDIDATES = {
-    "shipped (merge m6)": ({}, {}),
-    "conv4_2,4_3 m6 s=-2": (tab(m6=C4[1:]), {}),
-    "conv4_2,4_3 m6 s=-1": (tab(m6=C4[1:]), {"s6_of": {"conv4_1": -1, "conv4_2": -1}}),
-    "conv4_2,4_3 m6 s=-3": (tab(m6=C4[1:]), {"s6_of": {"conv4_1": -3, "conv4_2": -3}}),
+    "shipped r5 (merge m6; conv4 m8, plain weights)": ({}, {}),
+    "shipped r4 (merge m6)": (tab(x3=C4), {}),
+    "conv4_2,4_3 m6 s=-2 (conv4_1 x3)": (tab(m6=C4[1:], x3=C4[:1]), {}),
+    "conv4_2,4_3 m6 s=-1 (conv4_1 x3)": (tab(m6=C4[1:], x3=C4[:1]), {"s6_of": {"conv4_1": -1, "conv4_2": -1}}),
+    "conv4_2,4_3 m6 s=-3 (conv4_1 x3)": (tab(m6=C4[1:], x3=C4[:1]), {"s6_of": {"conv4_1": -3, "conv4_2": -3}}),
     "conv4 m6 s=-1": (tab(m6=C4), {"s6_of": {"conv3_3": -1, "conv4_1": -1, "conv4_2": -1}}),
     "conv4 m6 s=0": (tab(m6=C4), {"s6_of": {"conv3_3": 0, "conv4_1": 0, "conv4_2": 0}}),
     "conv4 m6 s=-2": (tab(m6=C4), {}),
@@ -46,10 +47,10 @@ CANDIDATES = {
     "conv4 b6 s=-1": (tab(b6=C4), {"s6_of": {"conv3_3": -1, "conv4_1": -1, "conv4_2": -1}}),
     "conv4 b6 s=-2": (tab(b6=C4), {}),
     "conv4 b6 s=-3": (tab(b6=C4), {"s6_of": {"conv3_3": -3, "conv4_1": -3, "conv4_2": -3}}),
-    "conv4 m8 (block-scaled weights)": (tab(m8=C4), {}),
-    "conv4 m8 s8=2, plain weights": (tab(m8=C4), {"s8_act": 2, "m8_block_scale": False}),
+    "conv4 m8 s8=0, block-scaled weights": (tab(m8=C4), {"s8_act": 0, "m8_block_scale": True}),
     "conv4 m8 s8=2": (tab(m8=C4), {"s8_act": 2}),
-    "conv4_2,4_3 m8": (tab(m8=C4[1:]), {}),
+    "conv4 m8 s8=3": (tab(m8=C4), {"s8_act": 3}),
+    "conv4_2,4_3 m8": (tab(m8=C4[1:], x3=C4[:1]), {}),
     "conv4+conv3 m8": (tab(m8=C4 + C3), {}),
     "conv4+conv3+conv2 m8": (tab(m8=C4 + C3 + C2), {}),
     "conv4+conv3+conv2+conv1_2,1_3 m8": (tab(m8=C4 + C3 + C2 + C1[1:]), {}),
