@@ -31,7 +31,7 @@ from surfacenet_amd import synthetic          # noqa: E402  (synthetic inputs of
 MEAN6 = synthetic.MEAN6
 
 DTYPE = {"f16m8": "f16 main term + 6-bit (fp6 e2m3, MX-scaled MFMA) correction terms in every layer, f32 accumulate (L_inf 1e-4 .. 4e-4); CVC warp f64",
-         "f16x3": "f16x3 (each operand = hi+lo fp16 pair, 3 MFMAs per product, f32 accumulate: fp32-class results; in the two merge layers the two correction terms run on one MX-scaled fp6 MFMA; L_inf vs fp64 oracle ~1e-4); CVC warp f64",
+         "f16x3": "f16x3 (each operand = hi+lo fp16 pair, 3 MFMAs per product, f32 accumulate: fp32-class results; the two correction terms of a product run on one MX-scaled MFMA in the two merge layers (fp6 e2m3 codes) and in the three dilated layers conv4_x (fp8 e4m3 codes); L_inf vs fp64 oracle 3e-5 .. 1.7e-4, asserted < 2e-4, bar 1e-3); CVC warp f64",
          "f16x3p": "f16x3 pure (each operand = hi+lo fp16 pair, 3 fp16 MFMAs per product in every layer, f32 accumulate); CVC warp f64",
          "f16": "f16 (MFMA, f32 accumulate); CVC warp f64"}
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: BF16/FP16 MFMA dense peak
@@ -457,7 +457,7 @@ def main():
         except Exception:
             pass
         out["roofline"]["note"] = ("achieved = ALGORITHMIC conv FLOPs / kernel time; the f16x3 mode issues 3 MFMA FLOPs per algorithmic "
-                                   "FLOP (1.5 in the two merge layers, whose correction terms run on the MX-scaled fp6 MFMA at twice the fp16 rate), so its ceiling is frac = 1/3 .. 2/3; peak = the nominal 2.5 PF at 2.4 GHz - a pure 16x16x32 MFMA stream sustains "
+                                   "FLOP (1.5 in the two merge layers, whose correction terms run on the MX-scaled fp6 MFMA at twice the fp16 rate; 2 in conv4_x, fp8 codes), so its ceiling is frac = 1/3 .. 2/3; peak = the nominal 2.5 PF at 2.4 GHz - a pure 16x16x32 MFMA stream sustains "
                                    "1,950-1,980 TF at 1.87 GHz on this chip (tools/probe/power_probe.hip, profiles/r4/power_probe_r4.txt)" if args.precision.startswith("f16x3") else "achieved = algorithmic conv FLOPs / kernel time")
         if world == 1 and args.precision == "f16x3" and not args.no_fast_mode:
             out["fast_mode_f16"] = fast_mode(surfacenet_amd, scene, values, s, n, n_vp, local_rank, max(3, args.steps // 2))
