@@ -111,8 +111,8 @@ def _packed_halfs(cin, ks, taps, cs8, split, nf, nsplit):
     not a multiple of 4 / 8, 3x3(x3) taps) run a slab's units on from where the slab before stopped and pad only the last slab."""
     groups = -(-cin // 8)
     slabs = [min(cs8, groups - g) for g in range(0, groups, cs8)]
-    um = 8 if split == 2 else 4
-    bridged = ks == 3 and split in (1, 2) and len(slabs) >= 2 and all(c == cs8 for c in slabs) and (taps * cs8) % um != 0
+    um = 8 if split >= 2 else 4
+    bridged = ks == 3 and split in (1, 2, 3) and len(slabs) >= 2 and all(c == cs8 for c in slabs) and (taps * cs8) % um != 0
     total = 0
     for si, c8n in enumerate(slabs):
         gu, o, b = taps * c8n, 0, 0
@@ -120,13 +120,14 @@ def _packed_halfs(cin, ks, taps, cs8, split, nf, nsplit):
             o = (si * ((um - gu % um) % um)) % um
             b = 0 if si + 1 == len(slabs) else (um - (gu - o) % um) % um
         total += -(-(gu - o + b) // um) * (um // 4)                      # in K-chunks
-    per_chunk = nf * 1024 if split == 2 else nf * 512 * (2 if split == 1 else 1)        # halfs per chunk (f16m8: 4 nf KiB per 2-chunk piece)
+    per_chunk = nf * 1024 if split >= 2 else nf * 512 * (2 if split == 1 else 1)        # halfs per chunk (f16m8: 4 nf KiB per 2-chunk piece)
     return total * per_chunk * nsplit, bridged, total
 
 
 @pytest.mark.parametrize("cin,cout,ks,k2d,nf,nsplit,cs8,split,chunks", [
     (32, 32, 3, 0, 2, 1, 1, 1, 27),        # conv1_2, f16x3: 4 slabs of 27 units = 27 chunks (28 padded)
-    (300, 300, 3, 0, 5, 4, 1, 1, 257),     # conv4_2: 38 slabs -> ceil(38 * 27 / 4)
+    (300, 300, 3, 0, 5, 4, 1, 1, 257),     # conv4_2 on three fp16 MFMAs (f16x3p): 38 slabs -> ceil(38 * 27 / 4)
+    (300, 300, 3, 0, 5, 4, 1, 3, 258),     # conv4_2, f16m8e (fp8 codes): 38 slabs = ceil(38 * 27 / 8) = 129 pieces = 258 chunks
     (64, 100, 3, 0, 7, 1, 1, 2, 54),       # merge_conv_a, f16m8: 8 slabs = 27 pieces (32 padded) = 54 chunks
     (100, 100, 3, 0, 7, 1, 1, 2, 88),      # merge_conv_b: 13 slabs = 44 pieces (52 padded)
     (64, 64, 3, 1, 4, 1, 2, 1, 18),        # similarityNet 64 -> 64, f16x3: 4 two-group slabs = 18 chunks (20 padded)

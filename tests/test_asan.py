@@ -44,9 +44,9 @@ for cin, cout, ks, dil, k2d, nf, nsplit in net + sim:
     taps = ks * ks * (1 if k2d else ks)
     W = (rs.randn(cout, cin, taps) * 10.0 ** rs.uniform(-6, 4)).astype(np.float32)          # any magnitude: the packer renormalises by powers of two
     bn = [rs.uniform(0.5, 1.5, cout).astype(np.float32) for _ in range(4)]
-    for split in (0, 1, 2):
-        if split == 2 and (ks == 1 or k2d):
-            continue                                                                          # f16m8 exists for the 3x3x3 kernels only
+    for split in (0, 1, 2, 3):
+        if split >= 2 and (ks == 1 or k2d):
+            continue                                                                          # f16m8 / f16m8e (fp8 codes: the dilated layers) exist for the 3x3x3 kernels only
         for cs8max in ((5,) if ks == 1 else ((2, 4) if k2d else (1, 2))):              # the slab widths the kernels are instantiated with
             out = (ctypes.c_ulonglong * 4)()
             rc = pack(cin, cout, ks, dil, k2d, nf, nsplit, cs8max, split, P(W), P(bn[0]), P(bn[1]), P(bn[2]), P(bn[3]), out)

@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--structured", action="store_true")
     ap.add_argument("--real", action="store_true", help="the real DTU scan9 / Middlebury dino pixel windows of tests/golden/real_cases.npz (CVC by the C oracle)")
+    ap.add_argument("--scene", action="store_true", help="cubes of the dataset scenes (tests/test_gpu_configs.py): partly out of view, heavy-tailed activations")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import synth
@@ -102,6 +103,20 @@ def main():
         for name, c in golden_util.real_cases().items():
             X = cvc_oracle.gen_coloredCubes(c["pairs"], c["xyz"], c["resol"], c["P"], golden_util.case_images(c), int(c["s"]), mean6=golden_util.MEAN6)
             cases.append(("real pixels %s (s=%d)" % (name, int(c["s"])), values, X))
+    if args.scene:
+        # cubes of the dataset scenes of tests/test_gpu_configs.py (dataset calibration + cube grid, noise views; partly out of view): their activations
+        # carry the outliers that decided round 5's conv4 question (the view pairs here are drawn at random, the scene's own come from the GPU pipeline)
+        import golden_util
+        from oracle import cvc_oracle
+        from surfacenet_amd import synthetic
+        values = list(synth.calibrated_params(1))
+        for cfg, picks, nvp in (("dtu_scan9", [0, 111, 222], 5), ("dino", [0, 120, 236], 6)):
+            P, imgs, cubes, _, _, _ = synthetic.dataset_scene(cfg, 32, 240)
+            rs = np.random.RandomState(3)
+            for pk in picks:
+                pairs = np.stack([np.sort(rs.choice(len(imgs), 2, replace=False)) for _ in range(nvp)])[None].astype(np.int64)
+                X = cvc_oracle.gen_coloredCubes(pairs, cubes["xyz"][pk:pk + 1], cubes["resol"][pk:pk + 1], P, imgs, 32, mean6=golden_util.MEAN6)
+                cases.append(("scene %s cube %d" % (cfg, pk), values, X))
     for label, values, X in cases:
         t0 = time.time()
         _, u64 = net_oracle.forward_torch(X, values, n_vp=1)
