@@ -179,7 +179,13 @@ class Context(object):
         pairs, xyz, resol, n, n_vp = self._batch_args(selected_viewPairs, xyz, resol)
         s = self.cube_D
         if n_vp > 1:
-            w = np.ascontiguousarray(w, dtype=np.float32).reshape(n, n_vp)
+            if w is None:
+                raise TypeError("cvc_forward: w (n, n_vp) float32 is required when a cube has more than one view pair (the reference passes 1/N_vp per pair "
+                                "when weighted fusion is off, main_reconstruct.py:114-115)")
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            if w.size != n * n_vp:
+                raise TypeError("cvc_forward: w must have shape (%d, %d), got %s" % (n, n_vp, w.shape))
+            w = w.reshape(n, n_vp)
         else:
             w = None
         m = np.ascontiguousarray(mean, dtype=np.float32).reshape(6)

@@ -289,3 +289,16 @@ def test_hot_loop_and_sparse_loop_calibrate_on_their_first_batch(dropin):
         loop.close()
         assert len([r for r in rec if issubclass(r.category, RuntimeWarning)]) == 1
     assert one[0] == first[0] and all(np.array_equal(a, b) for a, b in zip(one[2], first[2]))
+
+
+def test_cvc_forward_needs_weights_for_more_than_one_view_pair(gpu_required):
+    """Context.cvc_forward with N_vp >= 2 and no w used to die inside numpy ("cannot reshape array of size 1"); the reference's loop always passes w
+    (main_reconstruct.py:114-115, 145): a missing one is a TypeError that says so, before any device work."""
+    import surfacenet_amd
+    sc = golden_util.synthetic_scene(2, 2, s=16, seed=1, hw=(300, 400))
+    with surfacenet_amd.Context(cube_D=16, max_samples=4) as ctx:
+        ctx.set_cameras(sc["cams"]); ctx.set_images(sc["imgs"])
+        with pytest.raises(TypeError, match="w .n, n_vp. float32 is required"):
+            ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"])
+        with pytest.raises(TypeError, match="must have shape"):
+            ctx.cvc_forward(sc["pairs"], sc["xyz"], sc["resol"], np.ones((3,), np.float32))
