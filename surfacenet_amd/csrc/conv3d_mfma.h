@@ -19,9 +19,10 @@
 //                     still 5.3x the f32-input MFMA rate of gfx950 (no xf32/TF32 on this chip).
 //                     Activations live in HBM as two fp16 planes (hi, lo).
 //   SPLIT=2  "f16m8": the main term wh*xh on the f16 MFMA; the two correction terms wl*xh + wh*xl (2^-11 of it) on ONE
-//                     v_mfma_scale_f32_16x16x128_f8f6f4 per 64 k (fp8 e4m3 operands, lo parts pre-scaled by 2^12, the
-//                     2^-12 applied through the E8M0 block scale): 2 MFMA units per product instead of 3. L_inf vs the
-//                     fp64 oracle ~1e-4 (bar 1e-3). Second activation plane = [fp8(hi) x8 | fp8(lo*2^12) x8] per group.
+//                     v_mfma_scale_f32_16x16x128_f8f6f4 per 64 k on 6-bit operands (fp6 e2m3, mx_format.h: lo parts pre-scaled by 2^11, a static
+//                     per-tensor premultiplier on the activation side, one E8M0 scale per 32-element weight block), which issues at twice the fp8 rate:
+//                     1.5 MFMA units per product instead of 3 (the two merge layers of the default mode; every layer of the all-MX mode). Second
+//                     activation plane = 16-byte slots per voxel and group holding 16 six-bit codes [hi c0..3 | lo c0..3 | hi c4..7 | lo c4..7].
 //   SPLIT=3  "f16m8e" (round 5; the dilated layers conv4_x of the default mode): the same with fp8 e4m3 codes - 2 MFMA units per product, and the EXPONENT RANGE
 //                     the 6-bit codes lack: a static 6-bit premultiplier cannot hold the data-dependent outliers of the conv4 chain (profiles/r5/README.md).
 //                     Second activation plane = [fp8(hi * 2^s) x8 | fp8(lo * 2^12 * 2^s) x8] per group; weights as plain fp8 codes (no block scales).
