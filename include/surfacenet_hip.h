@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 1
+#define SN_ABI_VERSION 2   /* 2 (round 6): + sn_mfma_probe, sn_set_conv4_fp8; sn_calibrate_dev refuses the all-MX mode with SN_ERR_STATE (since round 5) */
 
 /* The library is built with -fvisibility=hidden: the functions below are its WHOLE dynamic symbol table
  * (tests/test_abi.py compares `nm -D` with this header). */
@@ -81,6 +81,11 @@ SN_API int sn_synchronize(sn_ctx *ctx);
 #define SN_PRECISION_F16X3_PURE 3
 SN_API int sn_set_precision(sn_ctx *ctx, int mode);
 SN_API int sn_get_precision(sn_ctx *ctx);
+/* SN_PRECISION_F16X3 only: on = 0 puts the dilated chain conv4_1 .. conv4_3 (nets/layers.py:200-253) back on three fp16 MFMAs per product - the
+ * round-4 arithmetic: worst observed L_inf 1.1e-4 instead of 1.7e-4, conv4_x 1.5 ms instead of 1.15 ms per 128 samples - while the merge layers
+ * keep their 6-bit correction step; on = 1 restores the default. Call after sn_set_precision (which resets it to 1) and before sn_load_weights
+ * (a change discards packed weights: SN_ERR_STATE from the forward calls until they are loaded again). */
+SN_API int sn_set_conv4_fp8(sn_ctx *ctx, int on);
 
 /* ---- one-time setup -------------------------------------------------------------------------- */
 /* Replaces lasagne.layers.set_all_param_values(...) in SurfaceNet_inference
@@ -261,9 +266,10 @@ SN_API int sn_comm_wait(sn_ctx *ctx, int slot);
 /* Variable-length all-gather of bytes - the exchange of the packed sparse voxel lists of a sharded scene (SURVEY §8e "counts then
  * all-gather-v"; utils/sparseCubes.py:9-77 produces the lists, main_reconstruct.py:153-160 accumulates them): every rank contributes
  * n_local bytes of device memory (0 allowed, different per rank); global_dev receives the contributions back to back in rank order and
- * counts[r] (host, `world` entries) their sizes. Synchronous. Every rank issues the same two collectives whatever its own arguments are: a
- * destination that cannot hold the total is reported AFTER the payload all-gather (SN_ERR_ARG, counts[] filled in) and must NOT be answered by
- * a retry of this rank alone. Size the destination first with sn_allgatherv_counts (collective: the 8-byte counts all-gather alone). */
+ * counts[r] (host, `world` entries) their sizes. Synchronous. Every rank issues the same collectives whatever its own arguments are (counts; one
+ * 8-byte status word per rank - a rank that cannot allocate its staging buffer says so there and EVERY rank returns the error without entering
+ * the payload step; payloads): a destination that cannot hold the total is reported AFTER the payload all-gather (SN_ERR_ARG, counts[] filled in)
+ * and must NOT be answered by a retry of this rank alone. Size the destination first with sn_allgatherv_counts (collective: the 8-byte counts all-gather alone). */
 SN_API int sn_allgatherv_counts(sn_ctx *ctx, size_t n_local, unsigned long long *counts);
 SN_API int sn_allgatherv_bytes_dev(sn_ctx *ctx, const void *local_dev, size_t n_local, void *global_dev, size_t global_cap,
                                    unsigned long long *counts);
@@ -277,6 +283,12 @@ SN_API int sn_profile_count(sn_ctx *ctx);
 SN_API int sn_profile_get(sn_ctx *ctx, int idx, char *name, int name_cap, double *ms_total, int64_t *launches,
                    double *flops, double *bytes);
 SN_API int sn_profile_reset(sn_ctx *ctx);
+/* What THIS box sustains on a pure stream of v_mfma_f32_16x16x32_f16 (all CUs, one wave per SIMD, random fp16 operands in registers): boxes of
+ * the same SKU fall into speed classes 5-8 % apart (power / clock management), and every absolute number of a run - cubes/s, kernel times,
+ * `roofline.frac` against the nominal 2.5 PF - moves with it. Runs a few launches of ~target_ms (<= 0: 10 ms) on the context's stream (DVFS settles
+ * within the first), returns the last one's rate in dense fp16 TFLOP/s and the shader clock it ran at (cycle counter / event time). Synchronous.
+ * No reference counterpart: measurement infrastructure (bench.py -> "box"). */
+SN_API int sn_mfma_probe(sn_ctx *ctx, double target_ms, double *tflops, double *ghz);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SURFACENET_HIP_LIB") or os.path.join(_HERE, "libsurfa
 
 # Every symbol include/surfacenet_hip.h declares (tests/test_abi.py checks the two lists agree).
 ABI_SYMBOLS = [
-    "sn_create", "sn_destroy", "sn_last_error", "sn_version", "sn_synchronize", "sn_set_precision", "sn_get_precision", "sn_stream",
+    "sn_create", "sn_destroy", "sn_last_error", "sn_version", "sn_synchronize", "sn_set_precision", "sn_get_precision", "sn_set_conv4_fp8", "sn_stream",
     "sn_load_weights", "sn_set_images", "sn_set_cameras",
     "sn_cvc", "sn_forward", "sn_cvc_forward", "sn_relative_weights", "sn_viewpair_weights", "sn_color_fuse", "sn_color_fuse_dev",
     "sn_dev_alloc", "sn_dev_free", "sn_memcpy_h2d", "sn_memcpy_d2h", "sn_mark", "sn_memcpy_d2h_after",
@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "sn_project_points",
     "sn_comm_unique_id", "sn_comm_init", "sn_comm_init_deadline", "sn_comm_info", "sn_allgather_f32_dev", "sn_allgather_f32_dev_overlap", "sn_comm_wait", "sn_allgatherv_counts", "sn_allgatherv_bytes_dev",
     "sn_calibrate_dev", "sn_numeric_status",
-    "sn_profile_enable", "sn_profile_count", "sn_profile_get", "sn_profile_reset",
+    "sn_profile_enable", "sn_profile_count", "sn_profile_get", "sn_profile_reset", "sn_mfma_probe",
 ]
 
 
@@ -72,6 +72,7 @@ def load():
         "sn_synchronize": (c_int, [c_void_p]),
         "sn_set_precision": (c_int, [c_void_p, c_int]),
         "sn_get_precision": (c_int, [c_void_p]),
+        "sn_set_conv4_fp8": (c_int, [c_void_p, c_int]),
         "sn_stream": (c_void_p, [c_void_p]),
         "sn_load_weights": (c_int, [c_void_p, c_void_p, c_size_t, P(ParamDesc), c_int]),
         "sn_set_images": (c_int, [c_void_p, c_int, P(c_void_p), P(c_int), P(c_int)]),
@@ -119,6 +120,7 @@ def load():
         "sn_profile_get": (c_int, [c_void_p, c_int, ctypes.c_char_p, c_int, P(ctypes.c_double), P(ctypes.c_int64),
                                    P(ctypes.c_double), P(ctypes.c_double)]),
         "sn_profile_reset": (c_int, [c_void_p]),
+        "sn_mfma_probe": (c_int, [c_void_p, ctypes.c_double, P(ctypes.c_double), P(ctypes.c_double)]),
     }
     assert sorted(sig) == sorted(ABI_SYMBOLS)
     for name, (res, args) in sig.items():

@@ -30,35 +30,78 @@ class NumericsGuard(object):
     scene / per call - reads the word; when more than `trigger_fraction` of a code plane's values saturate it calibrates on the batch that was just run, emits ONE `RuntimeWarning`
     naming the layers and the exponents chosen, and returns the calibration report: the caller then REDOES that batch (nets/SurfaceNet.py:385-402
     is where the only weights that will ever matter are loaded; main_reconstruct.py:145-146 is the call this protects). Afterwards the word is still
-    read (and cleared) but a calibrated context reports nothing more: the calibration itself tolerates `max_sat_fraction` of saturated values."""
+    read (and cleared) but a calibrated context reports nothing more: the calibration itself tolerates `max_sat_fraction` of saturated values.
+
+    What the guard KNOWS lives on the Context, next to the exponents it describes (`Context._numerics`): contexts are cached and shared
+    (runtime._contexts), `load_param_values` resets the exponents to the static ones - and with them this state, so a reused loop / callable watches
+    new weights afresh; two callers of one context see one calibration (a caller with auto_calibrate=False does not calibrate, but runs under whatever
+    exponents another caller of the same context set - `ctx.calibration_report()` says which). Cost: while the net stays clean the word is zero and a
+    check is one 8-byte read-back; a net that saturates a few per mille of its codes (every uncalibrated random net does) raises the word on every
+    batch, so after `BACKOFF_AFTER` measure-only probes below the trigger in a row the guard re-probes only every `BACKOFF_EVERY`-th check."""
+    FP8_PLANES = frozenset(("conv3_3", "conv4_1", "conv4_2"))      # tensors of the conv4 chain: fp8 e4m3 code planes (range 448, nothing to calibrate)
+    BACKOFF_AFTER, BACKOFF_EVERY = 3, 64
 
     def __init__(self, ctx, enabled=True, max_sat_fraction=1e-3, trigger_fraction=1e-2):
         self.ctx, self.enabled, self.max_sat_fraction, self.trigger_fraction = ctx, bool(enabled), float(max_sat_fraction), float(trigger_fraction)
-        self.calibrated, self.report, self.checks = False, None, 0
+        self.checks = 0
+
+    # (state shared by every guard of the context; reset by Context.load_param_values)
+    @property
+    def _st(self):
+        st = getattr(self.ctx, "_numerics", None)
+        if st is None:
+            st = self.ctx._numerics = Context._fresh_numerics()
+        return st
+
+    @property
+    def calibrated(self):
+        return self._st["calibrated"]
+
+    @property
+    def report(self):
+        return self._st["report"]
 
     def check(self, where="forward"):
         if not self.enabled:
             return None
         self.checks += 1
+        st = self._st
         names = self.ctx.numeric_status()
-        if not names or self.calibrated:
+        if not names or st["calibrated"]:
             return None
         import warnings
-        self.calibrated = True                   # one attempt, one warning per caller
-        if self.ctx.precision != "f16x3":
-            warnings.warn("surfacenet_amd (%s): stored activations of %s exceed the range of their 6-bit code planes; precision mode %r has no "
-                          "data-driven premultipliers - accuracy degrades towards plain fp16 for those values" % (where, ", ".join(names), self.ctx.precision),
+        fp8 = [n for n in names if n in self.FP8_PLANES]
+        if fp8 and not st["fp8_warned"]:
+            st["fp8_warned"] = True
+            warnings.warn("surfacenet_amd (%s): stored activations of %s exceed 256 * 2^-s: the fp8 correction codes of the dilated chain conv4_1 .. conv4_3 "
+                          "saturate for those values (each loses its own correction term; nothing to calibrate - fp8 has the range, the values are outliers of "
+                          "the net's BatchNorm statistics). Context(conv4_fp8=False) keeps the chain on three fp16 MFMAs." % (where, ", ".join(fp8)),
                           RuntimeWarning, stacklevel=3)
+        names = [n for n in names if n not in self.FP8_PLANES]
+        if not names:
+            return None
+        if self.ctx.precision != "f16x3":
+            if not st["mode_warned"]:
+                st["mode_warned"] = True
+                warnings.warn("surfacenet_amd (%s): stored activations of %s exceed the range of their 6-bit code planes; precision mode %r has no "
+                              "data-driven premultipliers - accuracy degrades towards plain fp16 for those values" % (where, ", ".join(names), self.ctx.precision),
+                              RuntimeWarning, stacklevel=3)
             return None
         # The warning word fires at the FIRST saturated value. Nets that roughly obey their BatchNorm statistics saturate a few per mille of
         # merge_conv_a's outputs (measured: 0.1 .. 0.3 % on uncalibrated random nets, 0.22 % on the worst structured input - L_inf unchanged at 5e-5);
         # the guard acts when more than `trigger_fraction` (1 %) of a plane's non-zero values saturate (x3.2 stress net: 5 %, L_inf 2e-4).
+        if st["clean_probes"] >= self.BACKOFF_AFTER:
+            st["skipped"] += 1
+            if st["skipped"] % self.BACKOFF_EVERY:
+                return None
         probe = self.ctx.calibrate(0, -1.0)
+        st["probes"] += 1
         if max(probe["sat_act_before"], probe["sat_cat_before"]) < self.trigger_fraction:
-            self.calibrated = False              # nothing to redo, nothing to report - the watch goes on
+            st["clean_probes"] += 1              # nothing to redo, nothing to report - the watch goes on (more and more sparsely)
             return None
+        st["clean_probes"] = 0
         cal = self.ctx.calibrate(0, self.max_sat_fraction)
-        self.report = cal
+        st["calibrated"], st["report"] = True, cal        # one calibration, one warning per set of weights
         warnings.warn("surfacenet_amd (%s): stored activations of %s exceeded the range of their 6-bit code planes (%.2f %% of merge_conv_a's non-zero "
                       "outputs, %.2f %% of the concat buffer; the network's BatchNorm statistics under-estimate their spread). Premultipliers "
                       "recalibrated on this batch: s_act %d -> %d, s_cat %d -> %d (saturated fraction now %.3f %% / %.3f %%); the batch is recomputed. "
@@ -71,9 +114,10 @@ class NumericsGuard(object):
 class Context(object):
     PRECISIONS = {"f16": 0, "f16x3": 1, "f16m8": 2, "f16x3p": 3}      # f16x3p: f16x3 without the MX tail (see surfacenet_hip.h)
 
-    def __init__(self, cube_D=32, max_samples=64, device=0, precision="f16x3"):
+    def __init__(self, cube_D=32, max_samples=64, device=0, precision="f16x3", conv4_fp8=True):
         """precision: "f16x3" (default; fp32-class results, operands as hi+lo fp16 pairs, 3 MFMAs per term) or
-        "f16" (3x faster, L_inf ~2e-3 vs the fp64 oracle on BN-normalised nets: above the 1e-3 parity bar)."""
+        "f16" (3x faster, L_inf ~2e-3 vs the fp64 oracle on BN-normalised nets: above the 1e-3 parity bar).
+        conv4_fp8=False (default mode only): the dilated chain conv4_1 .. conv4_3 back on three fp16 MFMAs (sn_set_conv4_fp8)."""
         if precision not in self.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
         self._lib = _lib.load()
@@ -83,8 +127,20 @@ class Context(object):
             raise _lib.SurfaceNetHipError("sn_create failed: %s" % _lib.last_error())
         self.precision = precision
         _lib.check(self._lib.sn_set_precision(self._h, self.PRECISIONS[precision]))
+        if not conv4_fp8 and precision == "f16x3":
+            _lib.check(self._lib.sn_set_conv4_fp8(self._h, 0))
         self.n_views = 0
         self.n_cameras = 0
+        self._numerics = self._fresh_numerics()
+
+    @staticmethod
+    def _fresh_numerics():
+        """What the NumericsGuards of this context know about the exponents in force (they are the static ones after every load_param_values)."""
+        return {"calibrated": False, "report": None, "clean_probes": 0, "skipped": 0, "probes": 0, "fp8_warned": False, "mode_warned": False}
+
+    def calibration_report(self):
+        """The report of the calibration the context runs under (None: the static premultipliers)."""
+        return self._numerics["report"]
 
     # ---- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -116,6 +172,7 @@ class Context(object):
         """values: the reference weight file's list of arrays (98 or 105, weights.PARAM_LAYOUT order)."""
         blob, descs = _weights.to_blob(values)
         _lib.check(self._lib.sn_load_weights(self._h, _lib.ptr(blob), blob.size, descs, len(values)))
+        self._numerics = self._fresh_numerics()          # sn_load_weights restored the static premultipliers: every guard of this context starts over
 
     def set_images(self, models_img):
         imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in models_img]
@@ -401,7 +458,10 @@ class Context(object):
         largest magnitudes). The setting holds until the next load_param_values / precision change."""
         cal = _lib.Calibration()
         _lib.check(self._lib.sn_calibrate_dev(self._h, int(n_samples), float(max_sat_fraction), ctypes.byref(cal)))
-        return {k: getattr(cal, k) for k, _ in _lib.Calibration._fields_}
+        out = {k: getattr(cal, k) for k, _ in _lib.Calibration._fields_}
+        if max_sat_fraction >= 0:                        # (a negative bound only measures)
+            self._numerics["calibrated"], self._numerics["report"] = True, out
+        return out
 
     def numeric_status(self):
         """Warning-level numeric status: names of the layers whose stored outputs exceeded the range of their 6-bit code plane since the last
@@ -462,14 +522,23 @@ class Context(object):
 
         def payload_fn(n_local, total):
             counts = (ctypes.c_ulonglong * world)()
-            d_all = self.dev_alloc(max(total, 16))
             try:
-                _lib.check(self._lib.sn_allgatherv_bytes_dev(self._h, d_local, int(n_local), d_all, int(total), counts))
+                d_all, alloc_err = self.dev_alloc(max(total, 16)), None
+            except _lib.SurfaceNetHipError as e:
+                # a rank that cannot hold the result must STILL run the call's collectives (its peers are entering them): with no destination the
+                # library runs them all and reports "too small" afterwards; the allocation failure is raised then
+                d_all, alloc_err = None, e
+            try:
+                rc = self._lib.sn_allgatherv_bytes_dev(self._h, d_local, int(n_local), d_all, int(total) if d_all else 0, counts)
+                if alloc_err is not None:
+                    raise alloc_err
+                _lib.check(rc)
                 out = np.empty((total,), dtype=np.uint8)
                 if total:
                     self.d2h(out, d_all)
             finally:
-                self.dev_free(d_all)
+                if d_all:
+                    self.dev_free(d_all)
             return [int(c) for c in counts], out
         try:
             return allgatherv_two_step(int(blob.size), counts_fn, payload_fn)
@@ -478,6 +547,12 @@ class Context(object):
                 self.dev_free(d_local)
 
     # ---- measurement --------------------------------------------------------------------------------
+    def mfma_probe(self, target_ms=10.0):
+        """What this box sustains on a pure fp16 MFMA stream (sn_mfma_probe) -> (dense fp16 TFLOP/s, shader clock in GHz)."""
+        tf, ghz = ctypes.c_double(), ctypes.c_double()
+        _lib.check(self._lib.sn_mfma_probe(self._h, float(target_ms), ctypes.byref(tf), ctypes.byref(ghz)))
+        return tf.value, ghz.value
+
     def profile_enable(self, on=True):
         _lib.check(self._lib.sn_profile_enable(self._h, 1 if on else 0))
 

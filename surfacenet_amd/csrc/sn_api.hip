@@ -636,6 +636,17 @@ int sn_set_precision(sn_ctx *c, int mode)
     return SN_OK;
 }
 
+// Public opt-out of the one arithmetic change of round 5: conv4_1 .. conv4_3 back on three fp16 MFMAs inside the default mode
+int sn_set_conv4_fp8(sn_ctx *c, int on)
+{
+    if (!c) return fail(SN_ERR_ARG, "null context");
+    if (c->mode != SN_PRECISION_F16X3) return fail(SN_ERR_STATE, "sn_set_conv4_fp8 applies to SN_PRECISION_F16X3 only (the other modes have no fp8 conv4 step)");
+    const int v = on ? 1 : 0;
+    if (v != c->c4_m8) { c->have_weights = false; c->last_run_samples = 0; }   // the conv4 weights are packed for the arithmetic they run in
+    c->c4_m8 = v;
+    return SN_OK;
+}
+
 int sn_get_precision(sn_ctx *c) { return c ? c->mode : SN_ERR_ARG; }
 void *sn_stream(sn_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
@@ -1274,6 +1285,16 @@ int sn_comm_info(char *file, int file_cap, int *version_code)
 // and the caller waits at most timeout_s for it; on a timeout the context stays without a communicator (SN_ERR_COMM), the helper thread - still
 // inside RCCL, where nothing can interrupt it - is abandoned together with the few bytes of state it owns, and the context remains usable for
 // everything but the exchange. sn_comm_init = the same without a deadline (the caller vouches that all ranks arrive).
+// The 8-byte-per-rank exchanges of sn_allgatherv_* (counts, per-rank status) run through a buffer that exists from the moment the communicator does:
+// an allocation that can fail must not sit between a rank and a collective its peers have already entered. [W slots | this rank's word]
+static int comm_small_alloc(sn_ctx *c)
+{
+    if (c->comm_small) { dev_free_owned(c, c->comm_small); c->comm_small = nullptr; }
+    int rc = dev_alloc(c, &c->comm_small, (size_t)(c->comm_world + 1) * 8);
+    if (rc != SN_OK) { comm_destroy_impl(c); c->comm_world = 0; c->comm_rank = 0; }      // no communicator without it: the caller falls back before any collective
+    return rc;
+}
+
 struct CommInitJob {
     std::mutex m; std::condition_variable cv;
     bool done = false; int err = 0; void *comm = nullptr; bool abandoned = false;
@@ -1295,7 +1316,7 @@ int sn_comm_init_deadline(sn_ctx *c, int world, int rank, const char *id128, dou
         const int e = ((init_fn)g_rccl.CommInitRank)(&c->rccl_comm, world, uid, rank);
         if (e != 0) { c->rccl_comm = nullptr; return fail(SN_ERR_COMM, "ncclCommInitRank: %s", rccl_err(e)); }
         c->comm_world = world; c->comm_rank = rank;
-        return SN_OK;
+        return comm_small_alloc(c);
     }
     auto job = std::make_shared<CommInitJob>();
     job->device = c->device; job->world = world; job->rank = rank;
@@ -1320,7 +1341,7 @@ int sn_comm_init_deadline(sn_ctx *c, int world, int rank, const char *id128, dou
     if (job->err != 0) return fail(SN_ERR_COMM, "ncclCommInitRank: %s", job->err == -1 ? "hipSetDevice failed in the helper thread" : rccl_err(job->err));
     c->rccl_comm = job->comm;
     c->comm_world = world; c->comm_rank = rank;
-    return SN_OK;
+    return comm_small_alloc(c);
 }
 
 int sn_comm_init(sn_ctx *c, int world, int rank, const char *id128) { return sn_comm_init_deadline(c, world, rank, id128, 0.0); }
@@ -1372,8 +1393,8 @@ int sn_comm_wait(sn_ctx *c, int slot)
 // (device memory; n_local may be 0 and may differ from rank to rank), global_dev receives the contributions back to back in rank order, counts[r]
 // (host, `world` entries) their sizes. Two RCCL all-gathers on the context's stream - the 8-byte counts, then the payloads padded to the largest -
 // and one device-to-device copy per rank that closes the gaps. Synchronous (the host needs the counts to size the second step).
-// EVERY rank issues the SAME sequence of collectives whatever its own arguments are: the only rank-local failure, a destination that cannot hold the
-// total, is reported AFTER the payload all-gather has run (SN_ERR_ARG with counts[] filled in), so a rank that fails never leaves its peers inside a
+// EVERY rank issues the SAME sequence of collectives (counts, an 8-byte status word per rank, payloads) whatever its own arguments are: a destination that
+// cannot hold the total is reported AFTER the payload all-gather has run (SN_ERR_ARG with counts[] filled in), so a rank that fails never leaves its peers inside a
 // collective it does not take part in (the first version returned between the two all-gathers, and a caller that retried on its own then
 // issued a counts all-gather against its peers' payload all-gather). sn_allgatherv_counts is the sizing query: the counts all-gather alone.
 static int comm_stage_need(sn_ctx *c, size_t bytes)
@@ -1386,19 +1407,19 @@ static int comm_stage_need(sn_ctx *c, size_t bytes)
     c->comm_stage_cap = bytes;
     return SN_OK;
 }
-static int comm_gather_counts(sn_ctx *c, size_t n_local, unsigned long long *counts)
+// one 8-byte word per rank, gathered to the host of every rank (counts; per-rank status)
+static int comm_gather_u64(sn_ctx *c, unsigned long long mine, unsigned long long *all, const char *what)
 {
     const int W = c->comm_world;
-    int rc = comm_stage_need(c, (size_t)(W + 1) * 8);
-    if (rc != SN_OK) return rc;
-    const unsigned long long mine = n_local;
-    HIPCHK(hipMemcpyAsync(c->comm_stage + (size_t)W * 8, &mine, 8, hipMemcpyHostToDevice, c->stream));
-    const int e = g_rccl.AllGather(c->comm_stage + (size_t)W * 8, c->comm_stage, 8, /*ncclUint8*/ 1, c->rccl_comm, c->stream);
-    if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather (counts): %s", rccl_err(e));
-    HIPCHK(hipMemcpyAsync(counts, c->comm_stage, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!c->comm_small) return fail(SN_ERR_STATE, "the communicator's exchange buffer is missing (sn_comm_init did not complete)");
+    HIPCHK(hipMemcpyAsync(c->comm_small + (size_t)W * 8, &mine, 8, hipMemcpyHostToDevice, c->stream));
+    const int e = g_rccl.AllGather(c->comm_small + (size_t)W * 8, c->comm_small, 8, /*ncclUint8*/ 1, c->rccl_comm, c->stream);
+    if (e != 0) return fail(SN_ERR_COMM, "ncclAllGather (%s): %s", what, rccl_err(e));
+    HIPCHK(hipMemcpyAsync(all, c->comm_small, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return SN_OK;
 }
+static int comm_gather_counts(sn_ctx *c, size_t n_local, unsigned long long *counts) { return comm_gather_u64(c, n_local, counts, "counts"); }
 
 int sn_allgatherv_counts(sn_ctx *c, size_t n_local, unsigned long long *counts)
 {
@@ -1420,8 +1441,18 @@ int sn_allgatherv_bytes_dev(sn_ctx *c, const void *local_dev, size_t n_local, vo
     for (int r = 0; r < W; ++r) { total += counts[r]; cap = std::max(cap, counts[r]); }
     if (total == 0) return SN_OK;                                  // (the same on every rank: nobody enters the payload step)
     cap = (cap + 15) & ~15ull;
-    rc = comm_stage_need(c, (size_t)(W + 1) * cap);              // [W padded payloads | this rank's padded payload]
+    // The staging buffer is sized by the LARGEST rank's payload, known only now - and its allocation is the one step between the two collectives that a
+    // single rank can fail. Its outcome is exchanged (8 bytes per rank) before anyone enters the payload all-gather: all ranks go on, or all
+    // ranks return the same error.
+    const int stage_rc = comm_stage_need(c, (size_t)(W + 1) * cap);              // [W padded payloads | this rank's padded payload]
+    const std::string stage_err = stage_rc != SN_OK ? g_err : std::string();
+    std::vector<unsigned long long> flags((size_t)W, 0);
+    rc = comm_gather_u64(c, stage_rc != SN_OK ? 1ull : 0ull, flags.data(), "status");
     if (rc != SN_OK) return rc;
+    for (int r = 0; r < W; ++r)
+        if (flags[(size_t)r])
+            return fail(stage_rc != SN_OK ? stage_rc : SN_ERR_NOMEM, "sn_allgatherv_bytes_dev: rank %d could not stage %llu bytes%s%s - no rank entered the payload all-gather",
+                        r, (unsigned long long)(W + 1) * cap, stage_err.empty() ? "" : ": ", stage_err.c_str());
     unsigned char *mine_pad = c->comm_stage + (size_t)W * cap;
     if (n_local) HIPCHK(hipMemcpyAsync(mine_pad, local_dev, n_local, hipMemcpyDeviceToDevice, c->stream));
     int e;

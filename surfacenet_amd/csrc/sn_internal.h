@@ -115,7 +115,8 @@ struct sn_ctx {
     hipStream_t comm_stream = nullptr;                               // collectives that overlap the kernels (sn_allgather_f32_dev_overlap)
     hipEvent_t comm_ev[8] = {};                                      // ... their completion, per caller slot; comm_fork: "the kernels so far are done"
     hipEvent_t comm_fork = nullptr;
-    unsigned char *comm_stage = nullptr; size_t comm_stage_cap = 0;  // sn_allgatherv_bytes_dev: counts + padded payloads of all ranks
+    unsigned char *comm_stage = nullptr; size_t comm_stage_cap = 0;  // sn_allgatherv_bytes_dev: padded payloads of all ranks
+    unsigned char *comm_small = nullptr;                             // ... its 8-byte-per-rank exchanges (counts, status): allocated with the communicator
     float *relw_W1 = nullptr, *relw_scale = nullptr, *relw_shift = nullptr, *relw_w2 = nullptr; float relw_b2 = 0;
     // activation workspace (channels-last fp16)
     _Float16 *x0 = nullptr, *a1 = nullptr, *b1 = nullptr, *cat = nullptr, *p1 = nullptr, *a2 = nullptr, *b2 = nullptr,
@@ -298,7 +299,9 @@ static int launch_conv(sn_ctx *c, const PackedConv &L, Act in, int in_cs, Act ou
         // saturation warning: only for tensors stored with a 6-bit code plane whose values are not bounded by construction (ReLU outputs)
         constexpr int OS = OSPLIT < 0 ? SPLIT : OSPLIT;
         if (EPI == EPI_STORE && OS >= 2 && L.act == 0) {
-            const _Float16 lim = (_Float16)std::min(60000.f, std::ldexp(OS >= 3 ? 448.f : (SN_MX_FMT == 2 ? 7.5f : 28.f), a.mx_out_e8 - 127));
+            // (fp8 planes: the hi code holds values up to 448 * 2^-s, but the lo code - lo * 2^12 * 2^s with |lo| <= half an ulp of the fp16 hi - can already
+            // saturate from |x| = 256 * 2^-s on (ulp 0.25: lo up to 0.125 -> 512 > 448); the warning starts where the first code can saturate. ADVICE r5)
+            const _Float16 lim = (_Float16)std::min(60000.f, std::ldexp(OS >= 3 ? 255.875f : (SN_MX_FMT == 2 ? 7.5f : 28.f), a.mx_out_e8 - 127));
             unsigned short bits; memcpy(&bits, &lim, 2);
             a.mx_sat_bits = bits;
         }

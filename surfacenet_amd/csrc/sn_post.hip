@@ -230,3 +230,70 @@ extern "C" int sn_project_points(sn_ctx *c, int V, const double *P, int n, const
     HIPCHK(hipStreamSynchronize(c->stream));
     return SN_OK;
 }
+
+// ---- box-speed probe (include/surfacenet_hip.h: sn_mfma_probe) ------------------------------------------------------------------------
+// A pure v_mfma_f32_16x16x32_f16 stream, operands in registers, 14 independent accumulators (no dependent-issue stalls), one wave per SIMD on
+// every CU: what the chip SUSTAINS (time, not clocks) - tools/probe/power_probe.hip's first row, inside the library so that every bench line can
+// carry its box's speed class.
+typedef _Float16 probe_half8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) mfma_probe_kernel(float *out, int iters, unsigned long long *clk)
+{
+    const int lane = threadIdx.x & 63;
+    probe_half8 a[4], b[4];
+    unsigned st = 12345u + 747796405u * (unsigned)(threadIdx.x + 1);
+    for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 8; ++e) {      // random operands in [-1, 1]: zero (or constant) operands draw less power and clock higher
+            st = st * 1664525u + 1013904223u; a[j][e] = (_Float16)(((int)(st >> 16) % 2001 - 1000) * 0.001f);
+            st = st * 1664525u + 1013904223u; b[j][e] = (_Float16)(((int)(st >> 16) % 2001 - 1000) * 0.001f);
+        }
+    probe_f32x4 acc[14] = {};
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 56; ++q) acc[q % 14] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q & 3], b[(q >> 2) & 3], acc[q % 14], 0, 0, 0);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = (unsigned long long)(t1 - t0);
+    float s = 0.f;
+    for (int q = 0; q < 14; ++q) s += acc[q][0];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)lane;
+}
+
+extern "C" int sn_mfma_probe(sn_ctx *c, double target_ms, double *tflops, double *ghz)
+{
+    if (!c || !tflops) return fail(SN_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (!(target_ms > 0)) target_ms = 10.0;
+    if (target_ms > 200.0) target_ms = 200.0;
+    const int cus = c->num_cus > 0 ? c->num_cus : 256;
+    float *out = nullptr;
+    unsigned long long *clk = nullptr;
+    int rc = dev_alloc(c, &out, (size_t)cus * 256);
+    if (rc != SN_OK) return rc;
+    rc = dev_alloc(c, &clk, 1);
+    if (rc != SN_OK) { dev_free_owned(c, out); return rc; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); dev_free_owned(c, out); dev_free_owned(c, clk); };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return fail(SN_ERR_HIP, "hipEventCreate failed"); }
+    // one wave-instruction = 2 * 16 * 16 * 32 FLOP; 4 waves per CU; ~16 clocks each at ~2 GHz: iterations of 56 MFMAs for target_ms
+    const double flop_iter = 2.0 * 16 * 16 * 32 * 56.0 * 4 * cus;
+    int iters = (int)(target_ms * 1e-3 * 2.0e9 / (56.0 * 16.1));
+    if (iters < 100) iters = 100;
+    float ms = 0.f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipError_t e = hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(256), 0, c->stream, out, iters, clk);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) { cleanup(); return fail(SN_ERR_HIP, "sn_mfma_probe: %s", hipGetErrorString(e)); }
+    }
+    unsigned long long h = 0;
+    if (hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(SN_ERR_HIP, "sn_mfma_probe: copy failed"); }
+    cleanup();
+    if (!(ms > 0.f)) return fail(SN_ERR_HIP, "sn_mfma_probe: no elapsed time");
+    *tflops = flop_iter * iters / (ms * 1e-3) / 1e12;
+    if (ghz) *ghz = (double)h / (ms * 1e-3) / 1e9;
+    return SN_OK;
+}

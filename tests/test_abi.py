@@ -41,7 +41,7 @@ def test_header_binding_and_library_agree(built):
 
 def test_version_and_no_gpu_fails_loudly(built):
     lib = built.load()
-    assert lib.sn_version() == 1
+    assert lib.sn_version() == 2          # include/surfacenet_hip.h SN_ABI_VERSION (2 since round 6: + sn_mfma_probe, sn_set_conv4_fp8)
     import ctypes
     try:
         hip = ctypes.CDLL("libamdhip64.so")

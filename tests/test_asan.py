@@ -17,7 +17,7 @@ import ctypes, sys
 import numpy as np
 lib = ctypes.CDLL(sys.argv[1])
 lib.sn_last_error.restype = ctypes.c_char_p
-assert lib.sn_version() == 1
+assert lib.sn_version() == 2
 lib.sn_create.restype = ctypes.c_void_p
 ctx = lib.sn_create(0, 32, 8)                       # no GPU here: must fail cleanly (message, no crash); on a GPU box it succeeds
 if ctx:

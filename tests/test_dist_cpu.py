@@ -175,7 +175,7 @@ def _scene_worker(rank, world, port, n, mode, q):
             raise ValueError("SN_ERR_RANGE stand-in on rank 1")
         return T._fake_loop(imgs, P, valid_cubes, vp, w)
 
-    rule = T._clustered if mode == "clustered" else None
+    rule = T._clustered if mode == "clustered" else (T._clustered8 if mode == "clustered8" else None)
     try:
         res = reconstruct.reconstruct_scene_sharded([], np.zeros((3, 3, 4)), T._scene_cubes(n), select_fn=lambda i, P, c: T._fake_select(i, P, c, rule),
                                                     loop_fn=loop_fn, gather_intermediates=(mode != "lean"))
@@ -197,15 +197,15 @@ def _same_scene(a, b, intermediates=True):
         assert len(a[k]) == len(b[k]) and all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(a[k], b[k])), k
 
 
-def _run_scene_ranks(n, mode, port_base):
+def _run_scene_ranks(n, mode, port_base, world=2):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = port_base + (os.getpid() + n) % 2000
-    procs = [ctx.Process(target=_scene_worker, args=(r, 2, port, n, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_scene_worker, args=(r, world, port, n, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -244,6 +244,32 @@ def test_sharded_scene_balances_the_valid_list_gloo():
         assert (lo, hi) == ((0, 5) if rank == 0 else (5, 9))
         for k in ("patches_embedding", "inScope_cubes_vs_views", "dissimilarity"):
             assert np.array_equal(full["local_select"][k], want[k][lo:hi]), k
+
+
+def _clustered8(g):
+    return g >= 37                                   # every valid cube lies in the LAST raw shard of an 8-rank cut of 40 cubes
+
+
+@pytest.mark.parametrize("n,mode", [(5, "full"), (40, "clustered8"), (21, "lean")])
+def test_sharded_scene_eight_ranks_gloo(n, mode):
+    """The node's real shape (Next #5): 8 ranks. n = 5: three ranks hold EMPTY raw shards and most valid-list shards are empty too;
+    n = 40, clustered: the 3 valid cubes all lie in rank 7's raw shard - the second cut hands them to three different ranks, five ranks run an empty
+    loop; n = 21: the lean exchange. Every rank must return the one-piece scene."""
+    rule = _clustered8 if mode == "clustered8" else None
+    want = _fake_scene([], None, _scene_cubes(n), rule)
+    res = _run_scene_ranks(n, mode, 41500, world=8)
+    assert [r for r, _, _ in res] == list(range(8))
+    for rank, full, counts in res:
+        assert not isinstance(full, str), full
+        _same_scene(full, want, intermediates=(mode != "lean"))
+        assert len(full["cubes_per_rank"]) == 8 and sum(a for a, _ in full["cubes_per_rank"]) == n
+        assert sum(b for _, b in full["cubes_per_rank"]) == int(want["validCubes"].sum())
+    if mode == "clustered8":
+        assert int(want["validCubes"].sum()) == 3 and not want["validCubes"][:37].any()
+        assert sorted(sum(c) for _, _, c in res) == [0, 0, 0, 0, 0, 1, 1, 1]
+        assert res[0][1]["cubes_per_rank"][7][0] == 5 and all(a == 5 for a, _ in res[0][1]["cubes_per_rank"])
+    if mode == "full":
+        assert [a for a, _ in res[0][1]["cubes_per_rank"]].count(0) == 3
 
 
 def test_sharded_scene_checks_its_arguments_before_any_work():

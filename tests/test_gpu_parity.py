@@ -451,3 +451,36 @@ def test_bridged_and_padded_k_order_agree(gpu_required, tmp_path):
     print("bridged vs padded K order, max |d|:", worst)
     assert worst["f16"] == 0.0                                   # the f16 mode is not bridged: identical
     assert 0.0 < worst["f16x3"] < 2e-4 and 0.0 < worst["f16m8"] < 1e-3        # different, and within each mode's parity tolerance of each other
+
+
+# The three worst inputs of the 202-case survey of round 6 (tools/linf_survey.py, profiles/r6/linf_survey_r6.log: noise 36, structured 12, real-pixel
+# windows shifted / flipped 48, scene cubes 100 incl. border cubes and N_vp = 5 / 16; max over them 1.83e-4, 99 % 1.68e-4) - all three are cubes at
+# the rim of a dataset grid, partly out of view, on test net 1. Pinned here at the UNCHANGED tolerance (Next #4).
+SURVEY_WORST = [("scene", (1, "dino", "last", 291892604)), ("scene", (1, "dtu_scan9", "last", 198232321)), ("scene5", (1, "dtu_scan9", "any", 813056440))]
+
+
+@pytest.mark.parametrize("family,key", SURVEY_WORST, ids=["dino_rim_cube", "dtu_rim_cube", "dtu_5_pairs"])
+def test_survey_worst_cases(sn, family, key):
+    import survey_inputs
+    from oracle import net_oracle
+    ctxs = {}
+
+    def cvc_ctx_for(tag, P, imgs):
+        if tag not in ctxs:
+            ctxs[tag] = sn.Context(cube_D=survey_inputs.S, max_samples=16)
+            ctxs[tag].set_cameras(P); ctxs[tag].set_images(imgs)
+        return ctxs[tag]
+    net, stress, X, label = survey_inputs.make_case(family, key, cvc_ctx_for)
+    values = survey_inputs.net_values(net, stress)
+    with sn.Context(cube_D=survey_inputs.S, max_samples=16) as ctx:
+        ctx.load_param_values(values)
+        _, unf = ctx.forward(X, None, n_vp=1)
+    with sn.Context(cube_D=survey_inputs.S, max_samples=16, conv4_fp8=False) as ctx:        # the public opt-out (sn_set_conv4_fp8): conv4 chain on three fp16 MFMAs
+        ctx.load_param_values(values)
+        _, unf_x3 = ctx.forward(X, None, n_vp=1)
+    for c in ctxs.values():
+        c.close()
+    _, u64 = net_oracle.forward_torch(X, values, n_vp=1)
+    e, e_x3 = float(np.abs(unf - u64).max()), float(np.abs(unf_x3 - u64).max())
+    print("%s: L_inf vs fp64 oracle %.3e (conv4 chain on three fp16 MFMAs: %.3e)" % (label, e, e_x3))
+    assert e < TOL_X3 and e_x3 < TOL_X3

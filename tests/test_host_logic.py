@@ -157,3 +157,73 @@ def test_interpolation_kernel_pinned_to_reference_W_5D():
     vals = weights.synthetic_param_values(0)
     ups = [v for (layer, p, shape), v in zip(weights.PARAM_LAYOUT, vals) if layer.endswith("_deconv")]
     assert [u.shape[2] for u in ups] == [3, 5, 5] and np.array_equal(ups[0], G["f2_W"]) and np.array_equal(ups[1], G["f4_W"])
+
+
+class _FakeNumericsCtx(object):
+    """Stand-in of a Context for the NumericsGuard's bookkeeping (no library call): `status` is what numeric_status() returns next, `sat` the saturated
+    fraction a measure-only calibrate reports."""
+    precision = "f16x3"
+
+    def __init__(self):
+        from surfacenet_amd.context import Context
+        self._numerics = Context._fresh_numerics()
+        self._fresh = Context._fresh_numerics
+        self.status, self.sat, self.calls = [], 0.0, []
+
+    def numeric_status(self):
+        self.calls.append("status")
+        return list(self.status)
+
+    def calibrate(self, n, frac):
+        self.calls.append("measure" if frac < 0 else "calibrate")
+        rep = dict(s_act_before=0, s_cat_before=2, s_act=(0 if frac < 0 else -2), s_cat=2, sat_act_before=self.sat, sat_cat_before=0.0, sat_act=0.0, sat_cat=0.0,
+                   max_act=20.0, max_cat=1.0)
+        if frac >= 0:
+            self._numerics["calibrated"], self._numerics["report"] = True, rep
+        return rep
+
+    def load_param_values(self):
+        self._numerics = self._fresh()
+
+
+def test_numerics_guard_state_lives_on_the_context():
+    """the guard's knowledge (calibrated / report / back-off) belongs to the Context whose exponents it describes - contexts are cached and
+    shared (runtime._contexts): two callers see ONE calibration, new weights reset it for every live guard, a clean-but-noisy net is probed more and
+    more sparsely, fp8-plane layers (nothing to calibrate) get one warning of their own."""
+    import warnings
+    from surfacenet_amd.context import NumericsGuard
+    ctx = _FakeNumericsCtx()
+    a, b = NumericsGuard(ctx), NumericsGuard(ctx)
+    assert a.check() is None and ctx.calls == ["status"]                       # clean word: one read-back, nothing else
+    ctx.status, ctx.sat = ["merge_conv_a"], 0.05
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        rep = a.check("loop")
+        assert rep is not None and rep["s_act"] == -2 and len(w) == 1 and "recalibrated" in str(w[0].message)
+        assert a.calibrated and b.calibrated and b.report is rep               # the other caller of the context knows
+        assert b.check() is None and a.check() is None and len(w) == 1         # calibrated: the word is read and cleared, nothing more
+    ctx.load_param_values()                                                    # new weights: static exponents again ...
+    assert not a.calibrated and not b.calibrated and a.report is None          # ... and every live guard watches them afresh
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert b.check() is not None and len(w) == 1
+    # a net that saturates a few per mille of its codes raises the word on every batch: measure-only probes, then back-off
+    ctx.load_param_values()
+    ctx.sat, ctx.calls = 0.002, []
+    for _ in range(3 + 2 * NumericsGuard.BACKOFF_EVERY):
+        assert a.check() is None
+    assert ctx.calls.count("measure") == 3 + 2 and ctx.calls.count("calibrate") == 0
+    ctx.sat = 0.2                                                              # it gets worse later: the sparse probe still catches it
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = [a.check() for _ in range(NumericsGuard.BACKOFF_EVERY)]
+        assert sum(g is not None for g in got) == 1 and len(w) == 1
+    # fp8 planes: warned once per set of weights, never calibrated
+    ctx.load_param_values()
+    ctx.status, ctx.calls = ["conv4_1", "conv3_3"], []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert a.check() is None and b.check() is None
+        assert len(w) == 1 and "fp8" in str(w[0].message) and "conv4_fp8=False" in str(w[0].message)
+    assert "measure" not in ctx.calls and "calibrate" not in ctx.calls
+    assert NumericsGuard(ctx, enabled=False).check() is None
