@@ -312,9 +312,16 @@ struct ConvCfg {
     static constexpr int NSEG = PWM ? (NSEG0 + NW_ - 1) / NW_ * NW_ : NSEG0;   // 1 KiB DMA segments per plane (one-wave-per-SIMD loop: the same number for every wave)
     static constexpr int XPLANE = NSEG * 1024;
     static constexpr int XBUF = XPLANE * NPL;
+#ifndef SN_PW_WB3
+#define SN_PW_WB3 0       // 1: one-wave-per-SIMD loop with a RING OF THREE weight-piece buffers where the LDS has room (the merge layers: 159 KB) - a piece's DMAs are issued two
+                          // pieces ahead and the per-piece wait lets the newest ones fly. Built and measured in round 6 (profiles/r6/ab_r6_wb3.log): bit-identical, merge_conv_b
+                          // 2.751 -> 2.793 ms, merge_conv_a 1.863 -> 1.861 - the per-piece vmcnt + barrier wait is the waves' skew at the barrier, not DMA latency. Off.
+#endif
     static constexpr bool CST_LDS = (EPI == EPI_STORE) && NF >= 7;   // wide store epilogues: keep scale/shift in LDS so the compiler's vmcnt(0) before their use cannot serialise the stores (measured: merge_conv_a -4 %, narrower layers +3..6 % -> off there)
     static constexpr int EPI_CONST = CST_LDS ? NF * 16 * 4 * 2 : 0;   // scale, shift of this cout split, fp32
-    static constexpr int LDS_BYTES = 2 * XBUF + 2 * WBUF + 2 * KTAB_N * 4 + EPI_CONST;
+    static constexpr int NWB = (SN_PW_WB3 && PWM && 2 * XBUF + 3 * WBUF + 2 * KTAB_N * 4 + EPI_CONST <= 160 * 1024) ? 3 : 2;      // weight-piece buffers
+    static constexpr int wb_next(int b) { return NWB == 3 ? (b == 2 ? 0 : b + 1) : (b ^ 1); }
+    static constexpr int LDS_BYTES = 2 * XBUF + NWB * WBUF + 2 * KTAB_N * 4 + EPI_CONST;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
     // two 4-wave workgroups per CU only when 256 registers per lane are plausibly enough (accumulators = MF*NF*4)
     static constexpr int WG_PER_CU = (LDS_BYTES <= 80 * 1024 && NW == 4 && MF * NF <= 32) ? 2 : 1;
@@ -342,11 +349,11 @@ conv3d_f16_mfma(ConvArgs a)
     constexpr int NPL = C::NPL;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     char *const xbuf = lds;                                   // [2][NPL][XPLANE]
-    char *const wbuf = lds + 2 * C::XBUF;                     // [2][WBUF]
-    int *const kbuf = reinterpret_cast<int *>(lds + 2 * C::XBUF + 2 * C::WBUF);   // [2][KOFF_N]  (PWM: [2][PW_TABS][KOFF_N])
+    char *const wbuf = lds + 2 * C::XBUF;                     // [NWB][WBUF]
+    int *const kbuf = reinterpret_cast<int *>(lds + 2 * C::XBUF + C::NWB * C::WBUF);   // [2][KOFF_N]  (PWM: [2][PW_TABS][KOFF_N])
     // epilogue constants live in LDS: a global load in the epilogue would make hipcc wait vmcnt(0), i.e. for every store
     // issued before it (measured: 21 us per tile of serialised store->load round trips in merge_conv_a)
-    float *const cst = reinterpret_cast<float *>(lds + 2 * C::XBUF + 2 * C::WBUF + 2 * C::KTAB_N * 4);   // [2][NF*16]
+    float *const cst = reinterpret_cast<float *>(lds + 2 * C::XBUF + C::NWB * C::WBUF + 2 * C::KTAB_N * 4);   // [2][NF*16]
 
     // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to hipcc: without the readfirstlane every
     // loop and LDS-DMA destination indexed by it becomes an EXEC-masked (waterfall) loop (guide T20)
@@ -618,6 +625,7 @@ conv3d_f16_mfma(ConvArgs a)
         write_koff(c8n, 0, 0);
         const int nch = wchunks_of(c8n, 0);
         stage_w(0, nch < C::PCH ? nch : C::PCH, 0);
+        if constexpr (C::NWB == 3) stage_w((size_t)C::PCH * NF * C::FRAG, C::PCH, 1);      // ring of three: the layer's second piece as well (every slab of such a layer holds >= 2 pieces)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         wg_barrier();
     }
@@ -770,14 +778,18 @@ conv3d_f16_mfma(ConvArgs a)
                     int p_opaque = p;
                     asm volatile("" : "+s"(p_opaque));
                     const bool first = p_opaque == 0;
-                    const unsigned wp = wbuf_a + wbi * C::WBUF, wpn = wbuf_a + (wbi ^ 1) * C::WBUF;
+                    const unsigned wp = wbuf_a + wbi * C::WBUF, wpn = wbuf_a + C::wb_next(wbi) * C::WBUF;
                     const bool more = p + 1 < npiece;
                     // the piece after this one: the slab's next, else the first piece of the next slab / tile (tap table and halo tile of the OTHER buffer)
                     const unsigned nk_a = more ? tab_a + (unsigned)(8 * (p + 1)) * 4 : ntab_a;
                     const unsigned nx_a = more ? xs_a : nxs_a;
-                    const size_t w_off = more ? woff + (size_t)(2 * p + 2) * NF * C::FRAG : (have_next ? nwoff : 0);
+                    // the weight piece fetched during this one: two buffers - the next piece; ring of three - the piece after next (the slab's, else piece 0 / 1 of the
+                    // next slab / tile: every slab holds at least two), into the buffer the PREVIOUS piece was read from (everybody left it at that piece's barrier)
+                    size_t w_off;
+                    if constexpr (C::NWB == 3) w_off = p + 2 < npiece ? woff + (size_t)(2 * p + 4) * NF * C::FRAG : (have_next ? nwoff : 0) + (size_t)(2 * (p + 2 - npiece)) * NF * C::FRAG;
+                    else w_off = more ? woff + (size_t)(2 * p + 2) * NF * C::FRAG : (have_next ? nwoff : 0);
                     const char *const wsrc = wsrc0 + w_off;
-                    const unsigned wdst_a = lds_addr(wbuf) + (unsigned)((wbi ^ 1) * C::WBUF + wave * 1024);
+                    const unsigned wdst_a = lds_addr(wbuf) + (unsigned)((C::NWB == 3 ? C::wb_next(C::wb_next(wbi)) : (wbi ^ 1)) * C::WBUF + wave * 1024);
                     const bool halo_now = p_opaque < 2;           // (pieces 0 and 1 of the slab carry the next halo tile's DMAs)
                     __amdgpu_buffer_rsrc_t rs_p = first ? rs_hi : rs_lo;
                     unsigned hdst_p = hdst + (first ? 0u : (unsigned)(HH * C::NW * 1024));
@@ -860,6 +872,14 @@ conv3d_f16_mfma(ConvArgs a)
                     // the one barrier of the piece: this wave's part of the next weight piece (issued a burst ago) and, from a slab's second piece on,
                     // of the next halo tile has landed; nobody reads this piece's weight buffer any more
                     PW_T(2);
+                    if constexpr (C::NWB == 3) {
+                        // the NEXT piece's weights were requested a whole piece ago; what this piece requested (WPW weight DMAs for the piece after next, and the HH halo
+                        // DMAs of a slab's first two pieces, interleaved with them) may stay in flight - the memory pipe returns in order. (A slab of only two pieces
+                        // must see its second halo plane before the next slab starts: no allowance there.)
+                        if (!halo_now) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(WPW) : "memory");
+                        else if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(WPW + HH) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     PW_T(3);
                     wg_barrier();
@@ -920,7 +940,7 @@ conv3d_f16_mfma(ConvArgs a)
                     if constexpr (SN_TIMING == 1) { t_vm += pwt[1] - pwt[0]; t_bar += pwt[2] - pwt[1]; ++n_piece; }
                     if constexpr (SN_TIMING == 2) { t_vm += pwt[3] - pwt[2]; t_bar += pwt[4] - pwt[3]; ++n_piece; }
                     if constexpr (SN_TIMING == 3) { t_vm += pwt[5] - pwt[4]; t_bar += pwt[5] - pwt[0]; ++n_piece; }
-                    wbi ^= 1;
+                    wbi = C::wb_next(wbi);
                 } while (++p < npiece);
                 if constexpr (SN_TIMING == 4) { t_rel = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_bar += t_rel - pws1; ++n_piece; if (last_slab) t_rel = 0; }
             } else
@@ -1765,6 +1785,7 @@ conv3d_f16_mfma(ConvArgs a)
         }
         if constexpr (SN_TIMING == 10) { const long long t_tile2 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_vm += t_tile2 - t_tile1; t_bar += t_tile1 - t_tile0; ++n_piece; }
     }
+    if constexpr (C::NWB == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the ring's look-ahead DMAs of the last pieces: nothing may land in LDS after the workgroup has left)
     bad |= sn_tracked_bad(trk_acc, trk_h);
     if (a.status && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, a.status_bit);
     if (a.status && a.mx_sat_bits != 0 && __builtin_amdgcn_ballot_w64(sn_tracked_max_bits(trk_h) > a.mx_sat_bits) != 0 && lane == 0) atomicOr(a.status + 1, a.status_bit);

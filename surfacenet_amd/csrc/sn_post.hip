@@ -251,8 +251,10 @@ __global__ void __launch_bounds__(256) mfma_probe_kernel(float *out, int iters, 
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int q = 0; q < 56; ++q) acc[q % 14] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q & 3], b[(q >> 2) & 3], acc[q % 14], 0, 0, 0);
+        for (int q = 0; q < 56; ++q)      // tied accumulators in the AGPR file: through the builtin hipcc rotates the 14 tuples through the file (80 register moves per pass)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[q % 14]) : "v"(a[q & 3]), "v"(b[(q >> 2) & 3]));
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // (inline-asm MFMAs: the wait states in front of the accumulator reads below are ours to keep)
     const long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = (unsigned long long)(t1 - t0);
     float s = 0.f;
