@@ -33,6 +33,14 @@ static int simil_cs8(int mode) { return mode == 0 ? 4 : 2; }
 #ifndef SN_SIM_NF8
 #define SN_SIM_NF8 2
 #endif
+// SN_SIM_MF8 (round 6, experiment): the 64-output layers of the 64x64 / 32x32 maps (s_conv1_1, s_conv1_2, s_conv2_2 in two cout splits) with EIGHT voxel fragments per wave over
+// one-group slabs - 16 patches x 8x8 pixels x 64 channels per workgroup: bursts of 96 instead of 48 MFMAs per segment, 24 instead of 32 operand reads and half the weight DMAs per
+// 96 MFMAs, the same halo bytes per MFMA
+#ifndef SN_SIM_MF8
+#define SN_SIM_MF8 0
+#endif
+#define SCONV16 3, 1, 8, kSimNF, EPI_STORE, SP, 1, 2, 8, 0, 1
+#define SCONV16P 3, 1, 8, kSimNF, EPI_POOL2D, SP, 1, 2, 8, 0, 1
 #define SCONV8 3, 1, 4, 8, EPI_STORE, SP, 1, 2, 8, 0, 1
 #define SCONV8P 3, 1, 4, 8, EPI_POOL2D, SP, 1, 2, 8, 0, 1
 static bool simil_wide(int i, int mode)
@@ -41,6 +49,7 @@ static bool simil_wide(int i, int mode)
     return SN_SIM_NF8 && mode == 1 && kSimStage[i] < 4 && kSimC[i + 1] >= 128 && (!last || (SN_SIM_NF8 >= 2 && kSimC[i + 1] >= 256));
 }
 static int simil_nf(int i, int mode = 0) { return kSimStage[i] == 4 || simil_wide(i, mode) ? 8 : kSimNF; }
+static bool simil_mf8(int i, int mode) { return SN_SIM_MF8 && mode == 1 && kSimStage[i] < 2 && !simil_wide(i, mode); }
 
 static int simil_mode(sn_ctx *c) { return c->split == 0 ? 0 : 1; }   // f16m8 contexts run this net in f16x3 (own workspace)
 
@@ -59,7 +68,7 @@ static int simil_pack(sn_ctx *c)
         L.bridge = (want == 1 && !no_bridge) ? 1 : 0;       // f16x3: two-group slabs = 4.5 K-chunks -> 9 chunks per slab pair (pack_conv_host decides per layer)
         const float *W = c->simil_host.data() + c->simil_descs[2 * i].offset, *b = c->simil_host.data() + c->simil_descs[2 * i + 1].offset;
         std::vector<float> one((size_t)L.cout, 1.f), zero((size_t)L.cout, 0.f);
-        if ((rc = pack_conv(c, L, W, b, one.data(), zero.data(), one.data(), simil_nf(i, want), L.cout / (16 * simil_nf(i, want)), kSimStage[i] == 4 ? 2 : (simil_wide(i, want) ? 1 : simil_cs8(want)), want)) != SN_OK) return rc;
+        if ((rc = pack_conv(c, L, W, b, one.data(), zero.data(), one.data(), simil_nf(i, want), L.cout / (16 * simil_nf(i, want)), kSimStage[i] == 4 ? 2 : ((simil_wide(i, want) || simil_mf8(i, want)) ? 1 : simil_cs8(want)), want)) != SN_OK) return rc;
     }
     c->simil_split = want;
     return SN_OK;
@@ -159,6 +168,9 @@ static int run_simil_t(sn_ctx *c, const SimilWs &w, int n)
             if constexpr (SN_SIM_NF8 >= 2 && SP == 1) {
                 if (simil_wide(i, 1)) { rc = launch_conv<SCONV8P>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n); done = true; }
             }
+            if constexpr (SN_SIM_MF8 && SP == 1) {
+                if (!done && simil_mf8(i, 1)) { rc = launch_conv<SCONV16P>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n); done = true; }
+            }
             if (!done)
             rc = st == 4 ? launch_conv<SCONV5P>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n)
                          : launch_conv<SCONVP>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
@@ -171,6 +183,14 @@ static int run_simil_t(sn_ctx *c, const SimilWs &w, int n)
         if constexpr (SN_SIM_NF8 && SP == 1) {
             if (simil_wide(i, 1)) {
                 rc = launch_conv<SCONV8>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
+                if (rc != SN_OK) return rc;
+                cur = out; cur_cs = kSimC[i + 1];
+                continue;
+            }
+        }
+        if constexpr (SN_SIM_MF8 && SP == 1) {
+            if (simil_mf8(i, 1)) {
+                rc = launch_conv<SCONV16>(c, c->sconv[i], cur, cur_cs, out, kSimC[i + 1], 0, kSimC[i + 1], nullptr, 1, H, n);
                 if (rc != SN_OK) return rc;
                 cur = out; cur_cs = kSimC[i + 1];
                 continue;
