@@ -41,12 +41,34 @@ CNN_FLOPS_PER_SAMPLE_S32 = 44511690752   # learned-conv FLOPs 
 KERNEL_SOURCES = ["conv3d_mfma.h", "mx_format.h", "cvc_warp.h", "elementwise.h", "sn_internal.h", "sn_api.hip"]
 
 
+def _strip_comments(text):
+    """C++ source without comments and with whitespace runs collapsed: what the compiler sees (string literals kept as they are)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_src_sha16():
-    """sha256[:16] over the sources the hot-path kernels are built from: stamps profiles/pmc_traffic.json (tools/pmc_traffic.py)."""
+    """sha256[:16] over the sources the hot-path kernels are built from, COMMENTS AND WHITESPACE STRIPPED: stamps profiles/pmc_traffic.json (tools/pmc_traffic.py).
+    A comment-only edit keeps the stamp (the kernels are the same); any change of code drops the traffic figure until the counters are collected again."""
     import hashlib
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "surfacenet_amd", "csrc", f), "rb").read())
+        h.update(_strip_comments(open(os.path.join(ROOT, "surfacenet_amd", "csrc", f), "r", encoding="utf-8", errors="replace").read()).encode("utf-8"))
     return h.hexdigest()[:16]
 
 

@@ -30,8 +30,8 @@
 //   A operand = weights, pre-packed on the host in fragment order (lane l: cout = l&15, k = (l>>4)*8 + j);
 //   B operand = activations of a (TX+2R)x(TY+2R)x(TZ+2R) halo tile, staged per channel slab in LDS and re-read
 //               for every one of the 27 taps through a per-slab tap-offset table;
-//   D         = lane l, reg r: voxel = l&15, cout = (l>>4)*4 + r  -> 4 consecutive channels per lane,
-//               stored as one 8-byte fp16x4 (per plane).
+//   D         = lane l, reg r: voxel = l&15, cout = (l>>4)*4 + r  -> 4 consecutive channels per lane = half of a voxel's 16-byte group; the store
+//               epilogues finish two voxel fragments together and exchange the halves (v_permlane16_swap): ONE 16-byte store per lane and plane.
 // Execution structure (v2):
 //   * PERSISTENT workgroups: grid = (#CUs x workgroups/CU, cout splits); each workgroup walks tiles
 //     blockIdx.x, +gridDim.x, ... so nothing is ever staged behind a cold start except its very first slab.
