@@ -297,6 +297,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if local_rank >= torch.cuda.device_count():      # launcher restricted the visible devices to one per rank
             local_rank = 0
+        if os.environ.get("BENCH_TEST_SHARE_GPU0"):      # tests only (tests/test_gpu_bench.py): every rank on device 0, whatever the box holds - the shared-GPU scenario
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

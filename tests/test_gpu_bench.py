@@ -72,7 +72,7 @@ def test_comm_init_deadline_and_info_one_rank(gpu_required):
 
 
 def _run_bench_ranks(world, extra, port, env_extra=None, timeout=900):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_TEST_SHARE_GPU0="1", **(env_extra or {}))      # (all ranks on device 0 even on a multi-GPU node)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--cubes", "8", "--no-fast-mode", "--no-cpu-baseline", "--no-s64",
            "--no-simil", "--no-post-pass", "--no-scenes"] + extra
