@@ -20,32 +20,69 @@ def patch2embedding(images_list, img_h_cubesCorner, img_w_cubesCorner, patch2emb
     Out-of-scope (cube, view) entries keep the embedding of an all-black patch (utils/earlyRejection.py:31-34)."""
     inScope_cubes_vs_views = np.zeros((N_cubes, N_views), dtype=bool)
     patch_allBlack = image.preprocess_patches(np.zeros((1, patchSize, patchSize, 3), dtype=np.float32), mean_BGR=patches_mean_bgr)
-    patches_embedding = np.zeros((N_cubes, N_views, D_embedding), dtype=np.float32)
-    patches_embedding[:, :] = patch2embedding_fn(np.ascontiguousarray(patch_allBlack))[0]
     fused = bool(getattr(patch2embedding_fn, "sn_gpu", False)) and patchSize == 64
+    embedding_allBlack = patch2embedding_fn(np.ascontiguousarray(patch_allBlack))[0]
+    if fused:
+        # (N_cubes, N_views, 128) float32 is 4.9 GB for DTU scan9's full bounding box: filling it with the black-patch embedding up front is 2.5 s of
+        # first-touch page faults and memory traffic with the GPU idle. The fused path below writes every row exactly once instead - a view's in-scope rows
+        # with its embeddings, its out-of-scope rows with the black-patch embedding - while the GPU embeds the next view (round 6).
+        patches_embedding = np.empty((N_cubes, N_views, D_embedding), dtype=np.float32)
+    else:
+        patches_embedding = np.zeros((N_cubes, N_views, D_embedding), dtype=np.float32)
+        patches_embedding[:, :] = embedding_allBlack
     if fused:
         ctx = runtime.any_context()
         runtime.bind_images(ctx, images_list)
     proj_h = np.stack([img_h_cubesCorner.min(axis=-1), img_h_cubesCorner.max(axis=-1)], axis=-1)
     proj_w = np.stack([img_w_cubesCorner.min(axis=-1), img_w_cubesCorner.max(axis=-1)], axis=-1)
     if fused:
-        # The GPU embeds view v+1 (one blocking C call in a worker thread; ctypes drops the GIL) while this thread scatters the rows of
-        # view v into the (cubes, views, 128) array - a strided 0.5 KB-per-row scatter that was ~15 % of the stage when done in line.
+        # The GPU embeds one view (one blocking C call in a worker thread; ctypes drops the GIL) while this thread does the host work of its neighbours: the
+        # in-scope test of the NEXT view (22 ms for 195,360 cubes) and the write-out of the PREVIOUS one - its in-scope rows take the embeddings, its
+        # out-of-scope rows the black-patch embedding (strided 0.5 KB rows, first touch of the 4.9 GB array). Nothing but the first view's in-scope test and
+        # the last view's write-out is left outside the GPU's shadow (round 6: the up-front fill and the 49 in-scope tests were 3.5 s of DTU scan9's 38 s).
+        import threading
         from concurrent.futures import ThreadPoolExecutor
-        for _view, _image in enumerate(images_list):
-            inScope_cubes_vs_views[:, _view] = image.img_hw_cubesCorner_inScopeCheck(
-                hw_shape=_image.shape[:2], img_h_cubesCorner=img_h_cubesCorner[_view], img_w_cubesCorner=img_w_cubesCorner[_view])
-        views = [v for v in range(len(images_list)) if inScope_cubes_vs_views[:, v].any()]
 
-        def embed(v):
+        def embed(v, started):
             centers = cubeCenter_hw[:, v, inScope_cubes_vs_views[:, v]]
-            return ctx.crop_embed(v, centers[0], centers[1], patches_mean_bgr)
+            ch, cw = np.ascontiguousarray(centers[0], dtype=np.float64), np.ascontiguousarray(centers[1], dtype=np.float64)
+            started.set()                      # from here on the worker is a few bytecodes away from the C call, which drops the GIL
+            return ctx.crop_embed(v, ch, cw, patches_mean_bgr)
+
+        def submit(pool, v):
+            # (the caller goes on to numpy calls that hold the GIL for tens of ms each: wait until the worker has done its Python-side preparation, so
+            # that the GPU is busy before this thread is)
+            started = threading.Event()
+            fut = pool.submit(embed, v, started)
+            started.wait()
+            return fut
+
+        def write_out(v, emb):
+            m = inScope_cubes_vs_views[:, v]
+            patches_embedding[m, v] = emb
+            patches_embedding[~m, v] = embedding_allBlack
         with ThreadPoolExecutor(max_workers=1) as pool:
-            pending = pool.submit(embed, views[0]) if views else None
-            for k, v in enumerate(views):
-                emb = pending.result()
-                pending = pool.submit(embed, views[k + 1]) if k + 1 < len(views) else None
-                patches_embedding[inScope_cubes_vs_views[:, v], v] = emb
+            inflight = None                                          # (view, future) of the call the GPU is working on
+            for v in list(range(len(images_list))) + [None]:
+                has = False
+                if v is not None:
+                    ins = image.img_hw_cubesCorner_inScopeCheck(hw_shape=images_list[v].shape[:2], img_h_cubesCorner=img_h_cubesCorner[v],
+                                                                img_w_cubesCorner=img_w_cubesCorner[v])
+                    inScope_cubes_vs_views[:, v] = ins
+                    has = bool(ins.any())
+                retired = None
+                if inflight is not None and (v is None or has):
+                    retired = (inflight[0], inflight[1].result())
+                    inflight = None
+                if v is not None:
+                    if has:
+                        inflight = (v, submit(pool, v))
+                    else:
+                        patches_embedding[:, v] = embedding_allBlack      # no cube projects into this view
+                if retired is not None:
+                    write_out(*retired)
+        for v in range(len(images_list), N_views):                   # (fewer images than views: the reference leaves those columns black)
+            patches_embedding[:, v] = embedding_allBlack
         return patches_embedding, inScope_cubes_vs_views
     for _view, _image in enumerate(images_list):
         _inScope = image.img_hw_cubesCorner_inScopeCheck(hw_shape=_image.shape[:2], img_h_cubesCorner=img_h_cubesCorner[_view],

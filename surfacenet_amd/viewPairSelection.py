@@ -42,25 +42,48 @@ def camera_centers(cameraPOs):
 
 def viewPairAngles_wrt_pts(cameraTs, pts_xyz):
     """Angle <c_i, p, c_j> for every 2-combination of views and every point: (N_pts, N_viewPairs)
-    (utils/camera.py:275-309; dtype follows the inputs exactly as there)."""
+    (utils/camera.py:275-309; dtype follows the inputs exactly as there). The dot products are formed component by component on contiguous arrays - the
+    same three products summed in the same order as the reference's `np.sum(np.multiply(u[:, i], u[:, j]), axis=-1)`, bit for bit, without its three
+    (N_pts, N_viewPairs, 3) temporaries (DTU scan9: 23,347 points x 1,176 pairs, 11x faster; round 6)."""
     cameraTs = np.asarray(cameraTs)
     pts_xyz = np.asarray(pts_xyz)
     v = pts_xyz[:, None, :] - cameraTs[None, ...]                           # (N_pts, N_views, 3)
     u = v / np.linalg.norm(v, axis=-1, ord=2, keepdims=True)
     pairs = k_combination_np(range(cameraTs.shape[0]), k=2)
-    cos = np.sum(np.multiply(u[:, pairs[:, 0]], u[:, pairs[:, 1]]), axis=-1)
-    return np.arccos(np.clip(cos, -1.0, 1.0))
+    if pairs.size == 0 or u.shape[0] == 0:
+        cos = np.sum(np.multiply(u[:, pairs[:, 0]], u[:, pairs[:, 1]]), axis=-1) if pairs.size else np.zeros((u.shape[0], 0), dtype=u.dtype)
+        return np.arccos(np.clip(cos, -1.0, 1.0))
+    p0, p1 = pairs[:, 0], pairs[:, 1]
+    ux, uy, uz = (np.ascontiguousarray(u[..., k]) for k in range(3))
+    cos = ux[:, p0] * ux[:, p1]
+    cos += uy[:, p0] * uy[:, p1]
+    cos += uz[:, p0] * uz[:, p1]
+    np.clip(cos, -1.0, 1.0, out=cos)
+    return np.arccos(cos, out=cos)
 
 
 def __argmaxN_viewPairs__(viewPairs, w_viewPairs, N_argmax):
     """viewPairs (P,2), w (N,P) -> (N, N_argmax, 2) pairs and (N, N_argmax) weights of the N_argmax largest weights
-    per cube, in ASCENDING weight order (utils/viewPairSelection.py:8-41)."""
+    per cube, in ASCENDING weight order (utils/viewPairSelection.py:8-41: `w.argsort(axis=1)[:, -N_argmax:]`).
+    Same result without sorting every row in full (DTU scan9: 23,347 valid cubes x 1,176 pairs - the full argsort was 1 s of the scene): the N largest by
+    `argpartition`, sorted among themselves; a row whose choice or order could depend on how argsort breaks TIES (equal values inside the selection or at
+    its boundary, NaNs) is redone by the reference's own expression."""
     viewPairs = np.asarray(viewPairs)
     w_viewPairs = np.asarray(w_viewPairs)
-    N_validCubes = w_viewPairs.shape[0]
-    indice_cube, _ = np.indices((N_validCubes, N_argmax))
-    indice_N_max = w_viewPairs.argsort(axis=1)[:, -1 * N_argmax:]
-    return viewPairs[indice_N_max], w_viewPairs[indice_cube, indice_N_max]
+    N_validCubes, P = w_viewPairs.shape
+    N_argmax = int(N_argmax)
+    if N_validCubes == 0 or N_argmax <= 0 or P < 8 * N_argmax:
+        indice_N_max = w_viewPairs.argsort(axis=1)[:, -1 * N_argmax:]
+    else:
+        part = np.argpartition(w_viewPairs, P - N_argmax, axis=1)[:, P - N_argmax:]
+        vals = np.take_along_axis(w_viewPairs, part, axis=1)
+        order = np.argsort(vals, axis=1, kind="stable")
+        indice_N_max = np.take_along_axis(part, order, axis=1)
+        vals = np.take_along_axis(vals, order, axis=1)
+        ties = (np.diff(vals, axis=1) == 0).any(axis=1) | ((w_viewPairs >= vals[:, :1]).sum(axis=1) != N_argmax)
+        if ties.any():
+            indice_N_max[ties] = w_viewPairs[ties].argsort(axis=1)[:, -1 * N_argmax:]
+    return viewPairs[indice_N_max], np.take_along_axis(w_viewPairs, indice_N_max, axis=1)
 
 
 argmaxN_viewPairs = __argmaxN_viewPairs__

@@ -227,3 +227,33 @@ def test_numerics_guard_state_lives_on_the_context():
         assert len(w) == 1 and "fp8" in str(w[0].message) and "conv4_fp8=False" in str(w[0].message)
     assert "measure" not in ctx.calls and "calibrate" not in ctx.calls
     assert NumericsGuard(ctx, enabled=False).check() is None
+
+
+def test_argmaxN_fast_path_equals_the_reference_expression_incl_ties():
+    """viewPairSelection.__argmaxN_viewPairs__ (utils/viewPairSelection.py:8-41) selects by argpartition since round 6; wherever the reference's
+    `w.argsort(axis=1)[:, -N:]` could break a tie its own way (equal weights inside the selection or at its boundary, NaN) the row is redone by
+    that very expression: results identical on random, heavily tied, constant and NaN-bearing weights."""
+    from surfacenet_amd import viewPairSelection as V
+    pairs = V.k_combination_np(range(49), 2)
+    rs = np.random.RandomState(3)
+
+    def ref(w, N):
+        ic, _ = np.indices((w.shape[0], N))
+        idx = w.argsort(axis=1)[:, -N:]
+        return pairs[idx], w[ic, idx]
+    for trial in range(6):
+        w = rs.rand(400, 1176).astype(np.float32)
+        if trial == 1:
+            w[:, 100:140] = w[:, :1]
+        if trial == 2:
+            w = np.round(w, 2)
+        if trial == 3:
+            w[5, 7] = np.nan; w[9, :] = 0.5
+        if trial == 4:
+            w[:] = 0.25
+        for N in (5, 16):
+            a, b = V.__argmaxN_viewPairs__(pairs, w, N), ref(w, N)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True), (trial, N)
+    w = rs.rand(7, 12).astype(np.float32)               # few pairs: the reference's expression itself
+    a, b = V.__argmaxN_viewPairs__(V.k_combination_np(range(5), 2)[:12] if False else np.arange(24).reshape(12, 2), w, 5), None
+    assert a[0].shape == (7, 5, 2) and np.all(np.diff(a[1], axis=1) >= 0)
