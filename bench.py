@@ -225,6 +225,13 @@ def simil_net(surfacenet_amd, ctx, scene, steps, n=2040):        # = one interna
         emb = ctx.crop_embed(0, ch, cw, mean)
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile(); ctx.profile_enable(False); ctx.profile_reset()
+    # the same through ONE call for 16 chunks (a DTU view holds ~126,000 in-scope cube centres = 62 chunks per call: sn_crop_embed runs them back to back, centres up and
+    # embeddings down once): what the early-rejection stage of a scene sees, without the per-step synchronisation of the 2,040-patch steps above
+    nb = 16 * n
+    chb, cwb = rs.uniform(0, H, nb), rs.uniform(0, W, nb)
+    t0 = time.perf_counter()
+    ctx.crop_embed(0, chb, cwb, mean)
+    dt_big = time.perf_counter() - t0
     flops_patch = sum(2.0 * (64 >> st) ** 2 * 9 * ci * co for (_, ci, co), st in zip(weights.SIMIL_CONVS, [0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4]))
     conv = {k: v for k, v in prof.items() if k.startswith("s_conv")}
     conv_ms = sum(v["ms"] for v in conv.values()) / steps
@@ -237,7 +244,7 @@ def simil_net(surfacenet_amd, ctx, scene, steps, n=2040):        # = one interna
     ref = simil_oracle.embedding_torch(X, values, dtype="float32")
     t_cpu = (time.perf_counter() - t0) / 4
     return {"value": round(n / dt, 1), "unit": "patches/s", "what": "crop + preprocess + similarityNet embedding, %d patches of one view per step, embeddings to host" % n,
-            "ms_per_step": round(dt * 1e3, 3), "gflop_per_patch": round(flops_patch / 1e9, 3),
+            "ms_per_step": round(dt * 1e3, 3), "one_call_of_16_chunks_patches_per_s": round(nb / dt_big, 1), "gflop_per_patch": round(flops_patch / 1e9, 3),
             "convs_tflops": round(flops_patch * n / (conv_ms * 1e-3) / 1e12, 1), "convs_ms_per_step": round(conv_ms, 3),
             "dominant": {"kernel": "conv3d_f16_mfma<K2D %s>" % dom, "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                          "achieved_tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1), "frac_of_f16_mfma_peak": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4)},

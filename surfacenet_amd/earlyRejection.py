@@ -44,10 +44,12 @@ def patch2embedding(images_list, img_h_cubesCorner, img_w_cubesCorner, patch2emb
         from concurrent.futures import ThreadPoolExecutor
 
         def embed(v, started):
-            centers = cubeCenter_hw[:, v, inScope_cubes_vs_views[:, v]]
-            ch, cw = np.ascontiguousarray(centers[0], dtype=np.float64), np.ascontiguousarray(centers[1], dtype=np.float64)
-            started.set()                      # from here on the worker is a few bytecodes away from the C call, which drops the GIL
-            return ctx.crop_embed(v, ch, cw, patches_mean_bgr)
+            try:
+                centers = cubeCenter_hw[:, v, inScope_cubes_vs_views[:, v]]
+                ch, cw = np.ascontiguousarray(centers[0], dtype=np.float64), np.ascontiguousarray(centers[1], dtype=np.float64)
+            finally:
+                started.set()                  # from here on the worker is a few bytecodes away from the C call, which drops the GIL (set even if the
+            return ctx.crop_embed(v, ch, cw, patches_mean_bgr)      # preparation raised: the caller must not wait for ever - it meets the exception in result())
 
         def submit(pool, v):
             # (the caller goes on to numpy calls that hold the GIL for tens of ms each: wait until the worker has done its Python-side preparation, so
