@@ -218,3 +218,40 @@ def test_marked_readback_sees_its_own_batch(gpu_required):
         ctx.d2h_after(0, got, keep)                             # an old mark stays valid: everything before it has long completed
         assert np.array_equal(got, b)
         ctx.dev_free(dev); ctx.dev_free(keep)
+
+
+def test_fused_early_rejection_with_cube_centres_sharing_a_pixel(gpu_required):
+    """earlyRejection.patch2embedding, fused path (round 6): every row of the (cubes, views, 128) array is written once - in-scope rows with the view's
+    embeddings, out-of-scope rows with the black-patch embedding - and cubes whose centre projections TRUNCATE to the same pixel of a view (utils/image.py:
+    160-169) are embedded once. Forced here: three cubes share their centre up to a fraction of a pixel, one is an exact duplicate, one view sees
+    nothing, one cube is out of every view; the result must equal the reference's three-step protocol (crop -> preprocess -> batched network calls on host
+    arrays) bit for bit."""
+    from surfacenet_amd import camera, earlyRejection, runtime, similarityNet, weights
+    runtime.reset()
+    cube_D_mm = np.float32(12.8)
+    P = golden_util.cameras()["P_dtu"][:4].copy()
+    P[:, :2, :] *= 0.5
+    imgs = [golden_util.synth_image(700 + v, 600, 800) for v in range(4)]
+    rs = np.random.RandomState(11)
+    N = 40
+    xyz = (rs.rand(N, 3) * [80, 80, 40] + [-40, -40, 590]).astype(np.float32)
+    xyz[7] = [2000, 2000, 100]                                             # out of every view
+    simil_values = weights.synthetic_simil_param_values(2)
+    p2e, _ = similarityNet.similarityNet_inference(None, (64, 64), param_values=simil_values)
+    ih, iw = camera.perspectiveProj_cubesCorner(P, xyz, cube_D_mm, return_int_hw=False)
+    ch, cw = camera.perspectiveProj(P, xyz + cube_D_mm / 2., return_int_hw=False)
+    centres = np.stack([ch, cw], axis=0)                                   # (2, views, cubes)
+    for dup, src, dh, dw in ((11, 3, 0.0, 0.0), (12, 3, 0.3, -0.0), (13, 3, 0.6, 0.4), (20, 19, 0.0, 0.0)):
+        base_h, base_w = np.floor(centres[0, :, src]) + 0.05, np.floor(centres[1, :, src]) + 0.05
+        centres[0, :, src], centres[1, :, src] = base_h, base_w
+        centres[0, :, dup], centres[1, :, dup] = base_h + dh, base_w + dw      # same truncated pixel in every view
+        ih[:, dup], iw[:, dup] = ih[:, src], iw[:, src]                          # ... and the same in-scope verdicts
+    ih[2] += 5000.0                                                        # view 2 sees no cube at all
+    assert getattr(p2e, "sn_gpu", False)
+    got, got_in = earlyRejection.patch2embedding(imgs, ih, iw, p2e, MEAN_BGR, N, 4, 128, patchSize=64, batchSize=7, cubeCenter_hw=centres)
+    want, want_in = earlyRejection.patch2embedding(imgs, ih, iw, lambda x: p2e(x), MEAN_BGR, N, 4, 128, patchSize=64, batchSize=7, cubeCenter_hw=centres)
+    assert np.array_equal(got_in, want_in) and not got_in[:, 2].any() and not got_in[7].any() and got_in[:, 0].sum() > 20
+    assert got_in[3, 0] and got_in[11, 0] and got_in[12, 0] and got_in[13, 0]
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[3, 0], got[12, 0]) and np.array_equal(got[3, 0], got[13, 0]) and np.array_equal(got[19, 1], got[20, 1])
+    assert not np.array_equal(got[3, 0], got[4, 0])
