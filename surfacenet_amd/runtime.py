@@ -5,7 +5,8 @@ import numpy as np
 from .context import Context, MEAN_CVC_RGBRGB  # noqa: F401
 
 DEFAULT_CUBE_D = 64        # params.py:65 (__cube_D = 64; {32, 64} are the supported sizes). The drop-in callables infer cube_D from X.shape.
-DEFAULT_MAX_SAMPLES = 64
+DEFAULT_MAX_SAMPLES = None  # None: by cube size - 128 cube-view-pair samples at s <= 32 (5.2 GB of workspace; 128 samples fill every layer's tile rounds on 256 CUs exactly),
+                            # 64 above (s = 64: 21 GB). An int overrides it for contexts created afterwards.
 _device = 0
 _contexts = {}
 _param_values = None
@@ -136,7 +137,7 @@ def bind_single_image(ctx, img):
 def context_for(cube_D, n_samples=1):
     key = (_device, int(cube_D))
     ctx = _contexts.get(key)
-    want = max(DEFAULT_MAX_SAMPLES, 1)
+    want = max(int(DEFAULT_MAX_SAMPLES), 1) if DEFAULT_MAX_SAMPLES else (128 if int(cube_D) <= 32 else 64)
     if ctx is None:
         ctx = Context(cube_D=cube_D, max_samples=want, device=_device)
         if _param_values is not None:

@@ -57,6 +57,7 @@ def run(argv):
     ap.add_argument("--cube-d", type=int, default=32)
     ap.add_argument("--n-vp", type=int, default=0)
     ap.add_argument("--max-cubes", type=int, default=0)
+    ap.add_argument("--max-samples", type=int, default=0, help="cube-view-pair samples the scene's context is sized for (0: 128, or 8 x n_vp above 8 view pairs)")
     ap.add_argument("--batch", type=int, default=0, help="cubes per SurfaceNet batch (default: max_samples / n_vp; the reference's is 14 at s=32, params.py:117-118)")
     a = ap.parse_args(argv)
     from surfacenet_amd import SurfaceNet, reconstruct, runtime, similarityNet, weights
@@ -66,7 +67,7 @@ def run(argv):
     t_build = time.perf_counter() - t0
     simil_values = weights.synthetic_simil_param_values(0)
     simil_values[28][:] = 3.0; simil_values[29][:] = -2.5          # puts the synthetic pair distances inside the accepted band
-    runtime.DEFAULT_MAX_SAMPLES = 128 if n_vp <= 8 else 8 * n_vp
+    runtime.DEFAULT_MAX_SAMPLES = a.max_samples or (128 if n_vp <= 8 else 8 * n_vp)
     p2e, pair_fn = similarityNet.similarityNet_inference(None, (64, 64), param_values=simil_values)
     relw_fn, _ = SurfaceNet.SurfaceNet_inference(n_vp, None, None, cube_D=a.cube_d, param_values=weights.synthetic_param_values(0))
     mean_bgr = np.asarray([103.939, 116.779, 123.68], dtype=np.float32)
