@@ -309,3 +309,45 @@ def test_calibrate_refuses_stale_or_foreign_activations(sn):
         ctx.forward(X[:2], None, n_vp=1)
         with pytest.raises(sn.SurfaceNetHipError, match="default precision mode"):
             ctx.calibrate(2)
+
+
+@pytest.mark.parametrize("spread", [80.0, 300.0])
+def test_fp8_code_planes_warn_where_their_lo_codes_can_first_saturate(sn, spread):
+    """The conv4 chain's tensors carry fp8 e4m3 code planes (round 5): nothing to calibrate, but a stored value beyond 256 * 2^-s can saturate its lo code
+    (lo * 2^12 up to 512 > 448) and loses its own correction term - the layer's WARNING bit must say so (limit 256, not the hi code's 448: ADVICE r5),
+    the error word must stay clear (the values are far inside fp16), the drop-in guard names the layer ONCE and offers the opt-out, and
+    `conv4_fp8=False` (sn_set_conv4_fp8) runs the same net without the plane, hence without the warning and at the default tolerance. BatchNorm statistics
+    of conv4_1 that under-estimate its spread `spread`-fold push its outputs there (the same values go to the fp64 oracle). x80: stored values of 256 .. 448
+    (lo codes at risk only) - the result stays inside the bar; x300: values beyond 448, where the HI codes saturate too and the correction term
+    `w_lo * x_hi` is wrong by the clipped amount: outside the bar (measured 1.2e-2) - which is exactly what the warning is for."""
+    import warnings
+    from surfacenet_amd.context import NumericsGuard
+    values, X, w, s, n, n_vp = _case(1)
+    ix = _index()
+    values[ix[("conv4_1", "inv_std")]] = values[ix[("conv4_1", "inv_std")]] * np.float32(spread)
+    f64, u64 = _oracle(values, X, w, n_vp)
+    with sn.Context(cube_D=s, max_samples=4) as ctx:
+        ctx.load_param_values(values)
+        assert ctx.numeric_status() == []
+        fused, unfused = ctx.forward(X, w, n_vp=n_vp)                     # no SN_ERR_RANGE: stored values of a few hundred are ordinary fp16 numbers
+        names = ctx.numeric_status()
+        assert "conv4_1" in names, names
+        guard = NumericsGuard(ctx)
+        ctx.forward(X, w, n_vp=n_vp)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            assert guard.check("test") is None                            # nothing to calibrate, nothing to redo
+            ctx.forward(X, w, n_vp=n_vp)
+            assert guard.check("test") is None
+        msgs = [str(r.message) for r in rec if "fp8" in str(r.message)]
+        assert len(msgs) == 1 and "conv4_1" in msgs[0] and "conv4_fp8=False" in msgs[0], [str(r.message) for r in rec]
+    e = float(np.abs(unfused - u64).max())
+    with sn.Context(cube_D=s, max_samples=4, conv4_fp8=False) as ctx:
+        ctx.load_param_values(values)
+        fused3, unfused3 = ctx.forward(X, w, n_vp=n_vp)
+        assert not [n_ for n_ in ctx.numeric_status() if n_.startswith("conv4") or n_ == "conv3_3"]
+    e3 = float(np.abs(unfused3 - u64).max())
+    print("conv4_1 outputs x%.0f out: L_inf vs fp64 oracle %.3e with the fp8 step (warned: %s), %.3e with conv4_fp8=False" % (spread, e, names, e3))
+    assert e3 < TOL
+    if spread < 100:
+        assert e < 1e-3
