@@ -81,10 +81,12 @@ SN_API int sn_synchronize(sn_ctx *ctx);
 #define SN_PRECISION_F16X3_PURE 3
 SN_API int sn_set_precision(sn_ctx *ctx, int mode);
 SN_API int sn_get_precision(sn_ctx *ctx);
-/* SN_PRECISION_F16X3 only: on = 0 puts the dilated chain conv4_1 .. conv4_3 (nets/layers.py:200-253) back on three fp16 MFMAs per product - the
- * round-4 arithmetic: worst observed L_inf 1.1e-4 instead of 1.7e-4, conv4_x 1.5 ms instead of 1.15 ms per 128 samples - while the merge layers
- * keep their 6-bit correction step; on = 1 restores the default. Call after sn_set_precision (which resets it to 1) and before sn_load_weights
- * (a change discards packed weights: SN_ERR_STATE from the forward calls until they are loaded again). */
+/* SN_PRECISION_F16X3 only: which layers of the dilated chain conv4_1 .. conv4_3 (nets/layers.py:200-253) compute their correction terms on the fp8 MX
+ * MFMA (2 MFMA units per product) instead of three fp16 MFMAs. on = 1 (default): all three - worst observed L_inf 1.83e-4 over the 202-input survey
+ * of round 6, conv4_x 1.15 ms per 128 samples; on = 2: conv4_2 and conv4_3 only (conv4_1 on three fp16 MFMAs: <= 1.54e-4 on the survey's worst
+ * inputs, +0.07 ms); on = 0: none - the round-4 arithmetic (<= 9.5e-5 on the same inputs, conv4_x 1.5 ms). The merge layers keep their 6-bit
+ * correction step in every setting. Call after sn_set_precision (which resets it to 1) and before sn_load_weights (a change discards packed
+ * weights: SN_ERR_STATE from the forward calls until they are loaded again). */
 SN_API int sn_set_conv4_fp8(sn_ctx *ctx, int on);
 
 /* ---- one-time setup -------------------------------------------------------------------------- */

@@ -117,7 +117,8 @@ class Context(object):
     def __init__(self, cube_D=32, max_samples=64, device=0, precision="f16x3", conv4_fp8=True):
         """precision: "f16x3" (default; fp32-class results, operands as hi+lo fp16 pairs, 3 MFMAs per term) or
         "f16" (3x faster, L_inf ~2e-3 vs the fp64 oracle on BN-normalised nets: above the 1e-3 parity bar).
-        conv4_fp8=False (default mode only): the dilated chain conv4_1 .. conv4_3 back on three fp16 MFMAs (sn_set_conv4_fp8)."""
+        conv4_fp8 (default mode only; sn_set_conv4_fp8): True / 1 = conv4_1 .. conv4_3 with their correction terms on the fp8 MX MFMA (default),
+        2 = conv4_2 and conv4_3 only, False / 0 = the whole chain back on three fp16 MFMAs."""
         if precision not in self.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
         self._lib = _lib.load()
@@ -127,8 +128,8 @@ class Context(object):
             raise _lib.SurfaceNetHipError("sn_create failed: %s" % _lib.last_error())
         self.precision = precision
         _lib.check(self._lib.sn_set_precision(self._h, self.PRECISIONS[precision]))
-        if not conv4_fp8 and precision == "f16x3":
-            _lib.check(self._lib.sn_set_conv4_fp8(self._h, 0))
+        if int(conv4_fp8) != 1 and precision == "f16x3":
+            _lib.check(self._lib.sn_set_conv4_fp8(self._h, int(conv4_fp8)))
         self.n_views = 0
         self.n_cameras = 0
         self._numerics = self._fresh_numerics()

@@ -641,7 +641,8 @@ int sn_set_conv4_fp8(sn_ctx *c, int on)
 {
     if (!c) return fail(SN_ERR_ARG, "null context");
     if (c->mode != SN_PRECISION_F16X3) return fail(SN_ERR_STATE, "sn_set_conv4_fp8 applies to SN_PRECISION_F16X3 only (the other modes have no fp8 conv4 step)");
-    const int v = on ? 1 : 0;
+    if (on < 0 || on > 2) return fail(SN_ERR_ARG, "sn_set_conv4_fp8: 0 (none), 1 (conv4_1 .. conv4_3, the default) or 2 (conv4_2 and conv4_3 only)");
+    const int v = on;
     if (v != c->c4_m8) { c->have_weights = false; c->last_run_samples = 0; }   // the conv4 weights are packed for the arithmetic they run in
     c->c4_m8 = v;
     return SN_OK;

@@ -478,9 +478,12 @@ def test_survey_worst_cases(sn, family, key):
     with sn.Context(cube_D=survey_inputs.S, max_samples=16, conv4_fp8=False) as ctx:        # the public opt-out (sn_set_conv4_fp8): conv4 chain on three fp16 MFMAs
         ctx.load_param_values(values)
         _, unf_x3 = ctx.forward(X, None, n_vp=1)
+    with sn.Context(cube_D=survey_inputs.S, max_samples=16, conv4_fp8=2) as ctx:            # conv4_1 alone on three fp16 MFMAs
+        ctx.load_param_values(values)
+        _, unf_2 = ctx.forward(X, None, n_vp=1)
     for c in ctxs.values():
         c.close()
     _, u64 = net_oracle.forward_torch(X, values, n_vp=1)
-    e, e_x3 = float(np.abs(unf - u64).max()), float(np.abs(unf_x3 - u64).max())
-    print("%s: L_inf vs fp64 oracle %.3e (conv4 chain on three fp16 MFMAs: %.3e)" % (label, e, e_x3))
-    assert e < TOL_X3 and e_x3 < TOL_X3
+    e, e_x3, e_2 = float(np.abs(unf - u64).max()), float(np.abs(unf_x3 - u64).max()), float(np.abs(unf_2 - u64).max())
+    print("%s: L_inf vs fp64 oracle %.3e (conv4 chain on three fp16 MFMAs: %.3e; conv4_1 alone: %.3e)" % (label, e, e_x3, e_2))
+    assert e < TOL_X3 and e_x3 < 1.2e-4 and e_2 < 1.7e-4
