@@ -38,7 +38,7 @@ class NumericsGuard(object):
     exponents another caller of the same context set - `ctx.calibration_report()` says which). Cost: while the net stays clean the word is zero and a
     check is one 8-byte read-back; a net that saturates a few per mille of its codes (every uncalibrated random net does) raises the word on every
     batch, so after `BACKOFF_AFTER` measure-only probes below the trigger in a row the guard re-probes only every `BACKOFF_EVERY`-th check."""
-    FP8_PLANES = frozenset(("conv3_3", "conv4_1", "conv4_2"))      # tensors of the conv4 chain: fp8 e4m3 code planes (range 448, nothing to calibrate)
+    FP8_PLANES = frozenset(("conv3_3", "conv4_1", "conv4_2"))      # tensors of the conv4 chain: fp8 e4m3 code planes (hi codes to 448 * 2^-s, lo codes safe to 256 * 2^-s: where the warning starts; nothing to calibrate)
     BACKOFF_AFTER, BACKOFF_EVERY = 3, 64
 
     def __init__(self, ctx, enabled=True, max_sat_fraction=1e-3, trigger_fraction=1e-2):
